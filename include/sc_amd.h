@@ -1,0 +1,141 @@
+/*
+ * sc_amd.h -- C ABI of libsc_amd.so: batched Paillier / DGK big-integer arithmetic on MI355X (gfx950).
+ *
+ * The reference (TNO-MPC/protocols.secure_comparison 4.4.0) has NO native/FFI boundary: its hot path
+ * is reached through the Python object API of the un-vendored scheme packages
+ * (tno.mpc.encryption_schemes.{paillier,dgk,templates,utils}, pyproject.toml:32-38) by operator
+ * overloading from Initiator.step_* / KeyHolder.step_*.  This header is therefore the boundary a
+ * maintainer would bind with ctypes underneath those scheme objects; every entry point names the
+ * reference call sites (file:line under /root/reference/src/tno/mpc/protocols/secure_comparison/,
+ * "SC/") whose arithmetic it replaces.  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - Big integers are canonical residues stored as little-endian arrays of uint32_t words; a batch is
+ *     a dense row-major array [count][nwords] in DEVICE memory (hipMalloc / sc_malloc / a torch tensor's
+ *     data_ptr()).  "dptr" parameters are device pointers; "hptr" parameters are host pointers.
+ *   - All functions return 0 on success or a negative sc_status; sc_last_error() gives the message.
+ *   - Calls are asynchronous on the context's stream (sc_ctx_set_stream) unless stated otherwise.
+ *   - No function falls back to host arithmetic: without a gfx950 device every call fails.
+ */
+#ifndef SC_AMD_H
+#define SC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sc_ctx sc_ctx;
+
+enum sc_status {
+  SC_OK = 0,
+  SC_ERR_ARG = -1,          /* bad argument (AssertionError / ValueError at the Python layer) */
+  SC_ERR_HIP = -2,          /* HIP runtime error */
+  SC_ERR_NOT_INVERTIBLE = -3, /* an element has no modular inverse (gmpy2/pow raise in the reference) */
+  SC_ERR_UNSUPPORTED = -4   /* modulus too large for the compiled configurations */
+};
+
+/* ---- context ------------------------------------------------------------------------------------ */
+int sc_ctx_create(int device_id, sc_ctx** out_ctx);
+void sc_ctx_destroy(sc_ctx* ctx);
+int sc_ctx_set_stream(sc_ctx* ctx, void* hip_stream);   /* hipStream_t; NULL = default stream */
+int sc_ctx_synchronize(sc_ctx* ctx);
+const char* sc_last_error(sc_ctx* ctx);
+int sc_abi_version(void);
+
+/* device memory helpers for callers that do not bring their own allocator */
+int sc_malloc(sc_ctx* ctx, size_t bytes, void** out_dptr);
+int sc_free(sc_ctx* ctx, void* dptr);
+int sc_memcpy_h2d(sc_ctx* ctx, void* dptr, const void* hptr, size_t bytes);
+int sc_memcpy_d2h(sc_ctx* ctx, void* hptr, const void* dptr, size_t bytes);
+
+/* ---- per-key setup (replaces what the scheme constructors precompute; [ext] Paillier/DGK __init__) ---- */
+/* Register an odd modulus (Paillier N, N^2, p^2, q^2; DGK n, p).  nwords = words of every residue array. */
+int sc_mod_create(sc_ctx* ctx, const uint32_t* n_hptr, int nwords, int* out_mod);
+int sc_mod_words(sc_ctx* ctx, int mod);
+/* Register an exponent shared by a whole batch (Paillier N or lambda, DGK v_p, 2^i, 3, ...). */
+int sc_exp_create(sc_ctx* ctx, const uint32_t* e_hptr, int ewords, int* out_exp);
+/* Register a constant residue (kept in Montgomery form on the device): g, g^-1, mu, N (mod N^2) ... */
+int sc_const_create(sc_ctx* ctx, int mod, const uint32_t* v_hptr, int nwords, int* out_const);
+/* Build the fixed-base table base^(d * 2^(window*j)) for exponents below 2^exp_bits
+ * (DGK h and g: the randomizers h^r of SC/initiator.py:153-154 and SC/keyholder.py:106-108). */
+int sc_fbt_create(sc_ctx* ctx, int mod, const uint32_t* base_hptr, int exp_bits, int window, int* out_fbt);
+
+/* ---- batched residue arithmetic (the ciphertext operator algebra) ---------------- */
+/* out[i] = a[i] * b[i] mod n.  Stride 0 broadcasts a single residue.  ct + ct (SC/initiator.py:254,
+ * 476-483, 563), ct * randomizer (every .randomize()). */
+int sc_modmul(sc_ctx* ctx, int mod, const uint32_t* a_dptr, int a_stride_words, const uint32_t* b_dptr,
+              int b_stride_words, uint32_t* out_dptr, uint64_t count);
+/* out[i] = a[i] * c mod n for a registered constant c (ct + int with int in {0,1}: SC/initiator.py:320,
+ * 476, 484, 531). */
+int sc_modmul_const(sc_ctx* ctx, int mod, const uint32_t* a_dptr, int cst, uint32_t* out_dptr, uint64_t count);
+/* out[i] = x[i]^e mod n [* mul_into[i]], e shared: Paillier rho^N mod N^2 (SC/initiator.py:109,
+ * SC/keyholder.py:126-128), c^lambda (SC/keyholder.py:195), w^(2^i) (SC/initiator.py:406), w_sum^3 (:480).
+ * x may be wider than the modulus (x_words > nwords): it is reduced first (DGK zero test works mod p). */
+int sc_modexp_shared(sc_ctx* ctx, int mod, int exp, const uint32_t* x_dptr, int x_words,
+                     const uint32_t* mul_into_dptr /* nullable */, uint32_t* out_dptr, uint64_t count);
+/* flags[i] = (x[i]^e mod n == 1): DGK.is_zero, SC/keyholder.py:249 (e = v_p, n = p). */
+int sc_modexp_shared_isone(sc_ctx* ctx, int mod, int exp, const uint32_t* x_dptr, int x_words,
+                           uint8_t* flags_dptr, uint64_t count);
+/* out[i] = base^e[i] mod n [* mul_into[i]] with the fixed-base table: DGK randomize / encrypt
+ * g^m h^r (SC/keyholder.py:106-108, 213, 231; SC/initiator.py:153-154). e: [count][ewords]. */
+int sc_fixedbase_pow(sc_ctx* ctx, int fbt, const uint32_t* e_dptr, int ewords,
+                     const uint32_t* mul_into_dptr /* nullable */, uint32_t* out_dptr, uint64_t count);
+/* out[i] = x[i]^e[i] mod n [* base^e2[i]] with per-element exponents of at most ebits bits:
+ * the blinding c_i^rho_i of SC/initiator.py:512 optionally fused with the randomizer h^r_i of :153-154. */
+int sc_modexp_var(sc_ctx* ctx, int mod, const uint32_t* x_dptr, const uint32_t* e_dptr, int ewords, int ebits,
+                  int fbt /* -1 = none */, const uint32_t* e2_dptr, int e2words, uint32_t* out_dptr,
+                  uint64_t count);
+/* out[i] = x[i]^-1 mod n (Montgomery's simultaneous inversion + an on-device binary extended GCD):
+ * ct * -1 / int - ct / ct - ct (SC/initiator.py:254, 320, 371, 466, 478, 531, 559).
+ * Synchronous.  On SC_ERR_NOT_INVERTIBLE *bad_index (nullable) is an index of a non-invertible element. */
+int sc_modinv(sc_ctx* ctx, int mod, const uint32_t* x_dptr, uint32_t* out_dptr, uint64_t count,
+              int64_t* bad_index);
+
+/* ---- Paillier pieces that are not plain residue products --------------------------------------- */
+/* out[i] = 1 + m[i] * N mod N^2 (g = N+1 encryption without randomness: unsafe_encrypt(..) of
+ * SC/initiator.py:256, 562; SC/keyholder.py:274-286).  mod_n2 = N^2, cst_n = sc_const_create(mod_n2, N).
+ * m: [count][m_words], any m < 2^(32 m_words) (reduction mod N is implicit). */
+int sc_paillier_encrypt_raw(sc_ctx* ctx, int mod_n2, int cst_n, const uint32_t* m_dptr, int m_words,
+                            uint32_t* out_dptr, uint64_t count);
+/* out[i] = ((x[i] - 1) / n) * k mod n for x[i] = 1 (mod n), x: [count][x_words]: the L function and the
+ * mu multiplication of Paillier.decrypt (SC/keyholder.py:195).  mod = N (or p, q for CRT), cst_k = mu. */
+int sc_paillier_l_mul(sc_ctx* ctx, int mod, int cst_k, const uint32_t* x_dptr, int x_words, uint32_t* out_dptr,
+                      uint64_t count);
+
+/* ---- plaintext-side word arithmetic of the two parties (HBM-bound helpers) ------------------------ */
+/* From r[count][nw] and the Paillier N: m1 = 2^l + r ([count][nw+1], SC/initiator.py:256), alpha = r mod 2^l
+ * (:270), alpha_tilde = (r - N) mod 2^l (:373), rsmall = [r < (N-1)/2] (:289, :559), rshift = r >> l (:562).
+ * alpha / alpha_tilde / rsmall are uint64 per item. l <= 64. */
+int sc_plain_alice(sc_ctx* ctx, const uint32_t* r_dptr, const uint32_t* n_hptr, int nw, int l, uint64_t count,
+                   uint32_t* m1_dptr, uint64_t* alpha_dptr, uint64_t* alpha_tilde_dptr, uint64_t* rsmall_dptr,
+                   uint32_t* rshift_dptr);
+/* From z[count][nw]: beta = z mod 2^l (SC/keyholder.py:196), dbit = [z < (N-1)/2] (:213), zeta1 = z >> l,
+ * zeta2 = (z + N) >> l if dbit else z >> l (:274-282). */
+int sc_plain_bob(sc_ctx* ctx, const uint32_t* z_dptr, const uint32_t* n_hptr, int nw, int l, uint64_t count,
+                 uint64_t* beta_dptr, uint64_t* dbit_dptr, uint32_t* zeta1_dptr, uint32_t* zeta2_dptr);
+
+/* ---- fused Initiator steps 4c-4h (SC/initiator.py:272-485) --------------------------------------- */
+/* Inputs, all bit-major: beta[l][count][nw], beta_inv[l][count][nw], d[count][nw], d_inv[count][nw]
+ * (DGK ciphertexts mod n and their inverses), alpha / alpha_tilde / rsmall / delta_a uint64 per comparison,
+ * cst_g / cst_ginv = registered g and g^-1.  Output c[l+1][count][nw] in the order c_-1, c_0 .. c_{l-1}
+ * (SC/initiator.py:484), not blinded. */
+int sc_dgk_step4(sc_ctx* ctx, int mod, int cst_g, int cst_ginv, int l, const uint32_t* beta_dptr,
+                 const uint32_t* beta_inv_dptr, const uint32_t* d_dptr, const uint32_t* d_inv_dptr,
+                 const uint64_t* alpha_dptr, const uint64_t* alpha_tilde_dptr, const uint64_t* rsmall_dptr,
+                 const uint64_t* delta_a_dptr, uint32_t* c_out_dptr, uint64_t count);
+
+/* ---- measurement -------------------------------------------------------------------------------- */
+/* Runs an on-device v_mad_u64_u32 issue-rate probe; returns lane-MACs per second (the VALU-integer peak
+ * used as the roofline denominator).  Synchronous. */
+int sc_peak_probe(sc_ctx* ctx, double* out_mac_per_s);
+/* Number of Montgomery limb-products (v_mad_u64_u32 lane operations) issued by library calls since the
+ * last reset -- counted on the host from the micro-programs, used for the roofline numerator. */
+int sc_mac_counter(sc_ctx* ctx, int reset, double* out_macs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SC_AMD_H */

@@ -1,0 +1,77 @@
+"""ctypes binding of libsc_amd.so (C ABI: include/sc_amd.h).  Fails loudly when the library is missing."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsc_amd.so")
+
+# every symbol include/sc_amd.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "sc_ctx_create", "sc_ctx_destroy", "sc_ctx_set_stream", "sc_ctx_synchronize", "sc_last_error", "sc_abi_version",
+    "sc_malloc", "sc_free", "sc_memcpy_h2d", "sc_memcpy_d2h",
+    "sc_mod_create", "sc_mod_words", "sc_exp_create", "sc_const_create", "sc_fbt_create",
+    "sc_modmul", "sc_modmul_const", "sc_modexp_shared", "sc_modexp_shared_isone", "sc_fixedbase_pow", "sc_modexp_var",
+    "sc_modinv", "sc_paillier_encrypt_raw", "sc_paillier_l_mul", "sc_plain_alice", "sc_plain_bob", "sc_dgk_step4",
+    "sc_peak_probe", "sc_mac_counter",
+]
+
+
+class ScError(RuntimeError):
+    """Raised when a library call fails (HIP error, unsupported size, ...)."""
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library.  There is no CPU fallback: a missing library is an error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ScError(
+            f"{LIB_PATH} not found: build it with `python -m protocols.secure_comparison_amd.build` "
+            "(hipcc --offload-arch=gfx950).  This package has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, u64, i64p = C.c_void_p, C.c_int, C.c_uint64, C.POINTER(C.c_int64)
+    ip = C.POINTER(C.c_int)
+    sig = {
+        "sc_ctx_create": (i32, [i32, C.POINTER(vp)]),
+        "sc_ctx_destroy": (None, [vp]),
+        "sc_ctx_set_stream": (i32, [vp, vp]),
+        "sc_ctx_synchronize": (i32, [vp]),
+        "sc_last_error": (C.c_char_p, [vp]),
+        "sc_abi_version": (i32, []),
+        "sc_malloc": (i32, [vp, C.c_size_t, C.POINTER(vp)]),
+        "sc_free": (i32, [vp, vp]),
+        "sc_memcpy_h2d": (i32, [vp, vp, vp, C.c_size_t]),
+        "sc_memcpy_d2h": (i32, [vp, vp, vp, C.c_size_t]),
+        "sc_mod_create": (i32, [vp, vp, i32, ip]),
+        "sc_mod_words": (i32, [vp, i32]),
+        "sc_exp_create": (i32, [vp, vp, i32, ip]),
+        "sc_const_create": (i32, [vp, i32, vp, i32, ip]),
+        "sc_fbt_create": (i32, [vp, i32, vp, i32, i32, ip]),
+        "sc_modmul": (i32, [vp, i32, vp, i32, vp, i32, vp, u64]),
+        "sc_modmul_const": (i32, [vp, i32, vp, i32, vp, u64]),
+        "sc_modexp_shared": (i32, [vp, i32, i32, vp, i32, vp, vp, u64]),
+        "sc_modexp_shared_isone": (i32, [vp, i32, i32, vp, i32, vp, u64]),
+        "sc_fixedbase_pow": (i32, [vp, i32, vp, i32, vp, vp, u64]),
+        "sc_modexp_var": (i32, [vp, i32, vp, vp, i32, i32, i32, vp, i32, vp, u64]),
+        "sc_modinv": (i32, [vp, i32, vp, vp, u64, i64p]),
+        "sc_paillier_encrypt_raw": (i32, [vp, i32, i32, vp, i32, vp, u64]),
+        "sc_paillier_l_mul": (i32, [vp, i32, i32, vp, i32, vp, u64]),
+        "sc_plain_alice": (i32, [vp, vp, vp, i32, i32, u64, vp, vp, vp, vp, vp]),
+        "sc_plain_bob": (i32, [vp, vp, vp, i32, i32, u64, vp, vp, vp, vp]),
+        "sc_dgk_step4": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64]),
+        "sc_peak_probe": (i32, [vp, C.POINTER(C.c_double)]),
+        "sc_mac_counter": (i32, [vp, i32, C.POINTER(C.c_double)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

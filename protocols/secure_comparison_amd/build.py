@@ -1,0 +1,35 @@
+"""Build libsc_amd.so (hipcc, gfx950) in-tree.  Used by __graft_entry__.build() and by hand."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "sc_lib.hip")
+OUT = os.path.join(HERE, "libsc_amd.so")
+DEPS = [os.path.join(HERE, "csrc", f) for f in ("sc_lib.hip", "sc_kernels.h", "sc_device.h", "sc_vm.h", "sc_xgcd.h")] + [
+    os.path.join(HERE, "..", "..", "include", "sc_amd.h")
+]
+
+
+def needs_build() -> bool:
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(d) > t for d in DEPS)
+
+
+def build_lib(force: bool = False, verbose: bool = True) -> str:
+    if not force and not needs_build():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", SRC, "-o", OUT]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    build_lib(force="--force" in sys.argv)

@@ -1,0 +1,256 @@
+// Device-side big-integer primitives for gfx950 (CDNA4).
+//
+// Number format inside a kernel ("limb form"): radix 2^29 limbs, S = G*L limbs per number, spread
+// over G adjacent lanes (a "group"), lane j of the group holding limbs j*L .. j*L+L-1 in VGPRs.
+// A 64-lane wave therefore works on 64/G numbers at once.  Why 29-bit limbs: on gfx950
+// v_mad_u64_u32 issues every 4 cycles per wave64 and nearly every other integer instruction (add
+// with carry, DPP move, 64-bit shift) costs about as much (tools/microbench/probe2.hip), so the
+// inner loop must be (almost) nothing but v_mad_u64_u32.  With 29-bit limbs a 64-bit column
+// accumulator absorbs 2L <= 54 products (54 * 2^58 < 2^64) with NO carry handling; carries are
+// resolved once per column when it leaves the lane.
+//
+// Montgomery form: R = 2^(29*S); R > 2^38 * n for every configuration, so operands may stay in
+// [0, 2n) between multiplications (no conditional subtraction inside exponentiation loops).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sc {
+
+constexpr int W = 29;
+constexpr uint32_t LMASK = (1u << W) - 1;
+
+// ---------------------------------------------------------------------------------------------
+// cross-lane helpers (DPP; a group never straddles a 16-lane DPP row because G divides 16)
+// ---------------------------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ uint32_t bcast0(uint32_t v) {  // value of the group's lane 0
+  if constexpr (G == 1) {
+    return v;
+  } else if constexpr (G == 2) {
+    return __builtin_amdgcn_update_dpp(0u, v, 0xA0, 0xf, 0xf, false);  // quad_perm:[0,0,2,2]
+  } else if constexpr (G == 4) {
+    return __builtin_amdgcn_update_dpp(0u, v, 0x00, 0xf, 0xf, false);  // quad_perm:[0,0,0,0]
+  } else if constexpr (G == 16) {
+    return __builtin_amdgcn_update_dpp(0u, v, 0x150, 0xf, 0xf, false);  // row_newbcast:0
+  } else {
+    static_assert(G == 8, "unsupported group size");
+    uint32_t lo = __builtin_amdgcn_update_dpp(0u, v, 0x150, 0xf, 0x3, false);  // lanes 0-7  <- lane 0
+    return __builtin_amdgcn_update_dpp(lo, v, 0x158, 0xf, 0xc, false);         // lanes 8-15 <- lane 8
+  }
+}
+// lane i receives lane i+1 of its 16-lane row (row end: 0)
+__device__ __forceinline__ uint32_t row_from_above(uint32_t v) {
+  return __builtin_amdgcn_update_dpp(0u, v, 0x101, 0xf, 0xf, true);  // row_shl:1
+}
+// lane i receives lane i-1 of its 16-lane row (row start: 0)
+__device__ __forceinline__ uint32_t row_from_below(uint32_t v) {
+  return __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, true);  // row_shr:1
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-thread view of the group it belongs to.
+// ---------------------------------------------------------------------------------------------
+template <int G_, int L_>
+struct Grp {
+  static constexpr int G = G_, L = L_, S = G_ * L_, NG = 64 / G_;
+  static constexpr int SP = S + 3;                      // padded limb-array stride in LDS (odd)
+  static constexpr int WP = (W * S + 31) / 32 + 2;      // 32-bit-word scratch stride in LDS
+  int lane, g, j;                                       // lane in wave, group in wave, lane in group
+  uint32_t notTop, notBot;                              // 0 for the top / bottom lane of the group
+  uint32_t n[L];                                        // modulus limbs of this lane
+  uint32_t n0inv;                                       // -n^-1 mod 2^29
+
+  __device__ __forceinline__ void init(const uint32_t* __restrict__ n_limbs, uint32_t n0inv_) {
+    lane = threadIdx.x & 63;
+    g = lane / G;
+    j = lane % G;
+    notTop = (j == G - 1) ? 0u : ~0u;
+    notBot = (j == 0) ? 0u : ~0u;
+    n0inv = n0inv_;
+#pragma unroll
+    for (int l = 0; l < L; l++) n[l] = n_limbs[j * L + l];
+  }
+
+  __device__ __forceinline__ uint32_t from_above(uint32_t v) const {
+    if constexpr (G == 1) return 0u; else return row_from_above(v) & notTop;
+  }
+  __device__ __forceinline__ uint32_t from_below(uint32_t v) const {
+    if constexpr (G == 1) return 0u; else return row_from_below(v) & notBot;
+  }
+
+  // -------------------------------------------------------------------------------------------
+  // Montgomery product r = a * b / R mod n (lazily reduced: r < 2n, limbs < 2^29 + 2^7).
+  //   a: S limbs in LDS (the group's staging area), b: this lane's L limbs.
+  //   MODE 0: full product.  MODE 1: reduction only (a ignored, computes b / R mod n).
+  //   MODE 2: like 1 and additionally collects the Montgomery quotient digits into quot[] (lane k
+  //           keeps digits k*L..k*L+L-1); quot = -b / n mod R, which is how exact division is done.
+  // -------------------------------------------------------------------------------------------
+  template <int MODE>
+  __device__ __forceinline__ void mont(uint32_t (&r)[L], const uint32_t* a_lds, const uint32_t (&b)[L],
+                                       uint32_t (&quot)[L]) const {
+    uint64_t T[L];
+#pragma unroll
+    for (int i = 0; i < L; i++) T[i] = (MODE == 0) ? 0ull : (uint64_t)b[i];
+#pragma unroll 1
+    for (int k = 0; k < G; k++) {
+      uint32_t av[L];
+      if constexpr (MODE == 0) {
+#pragma unroll
+        for (int l = 0; l < L; l++) av[l] = a_lds[k * L + l];
+      }
+#pragma unroll
+      for (int l = 0; l < L; l++) {
+        if constexpr (MODE == 0) {
+          const uint32_t ai = av[l];
+#pragma unroll
+          for (int c = 0; c < L; c++) T[(l + c) % L] += (uint64_t)ai * b[c];
+        }
+        uint32_t q = ((uint32_t)T[l] * n0inv) & LMASK;
+        q = bcast0<G>(q);
+        if constexpr (MODE == 2) quot[l] = (j == k) ? q : quot[l];
+#pragma unroll
+        for (int c = 0; c < L; c++) T[(l + c) % L] += (uint64_t)q * n[c];
+        const uint64_t t0 = T[l];                 // column 0: its low 29 bits are 0 in lane 0
+        T[(l + 1) % L] += t0 >> W;                // carry into column 1
+        T[l] = (uint64_t)from_above((uint32_t)t0 & LMASK);  // becomes the new top column
+      }
+    }
+    // one local carry pass + hand the lane carry to the next lane (result "almost normalised")
+    uint64_t c = 0;
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+      const uint64_t v = T[l] + c;
+      r[l] = (uint32_t)v & LMASK;
+      c = v >> W;
+    }
+    if constexpr (G > 1) {
+      const uint32_t clo = from_below((uint32_t)c), chi = from_below((uint32_t)(c >> 32));
+      const uint64_t v = (uint64_t)r[0] + (((uint64_t)chi << 32) | clo);
+      r[0] = (uint32_t)v & LMASK;
+      r[1] += (uint32_t)(v >> W);
+    }
+  }
+  __device__ __forceinline__ void mul(uint32_t (&r)[L], const uint32_t* a_lds, const uint32_t (&b)[L]) const {
+    uint32_t dummy[L];
+    mont<0>(r, a_lds, b, dummy);
+  }
+  __device__ __forceinline__ void redc(uint32_t (&r)[L], const uint32_t (&b)[L]) const {
+    uint32_t dummy[L];
+    mont<1>(r, nullptr, b, dummy);
+  }
+
+  // -------------------------------------------------------------------------------------------
+  // Exact normalisation: r (entries < 2^32, any lazy form) minus sub[] (may be all zero) ->
+  // limbs in [0, 2^29).  Precondition: the represented value is in [0, R).
+  // -------------------------------------------------------------------------------------------
+  __device__ __forceinline__ void normalize(uint32_t (&r)[L], const uint32_t (&sub)[L]) const {
+    int64_t c = 0;
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+      const int64_t v = (int64_t)r[l] - (int64_t)sub[l] + c;
+      r[l] = (uint32_t)v & LMASK;
+      c = v >> W;
+    }
+    if constexpr (G > 1) {
+      int32_t cin = (int32_t)from_below((uint32_t)(int32_t)c);
+      while (__any(cin != 0)) {  // wave-uniform loop; at most G further rounds
+        int64_t cc = cin;
+#pragma unroll
+        for (int l = 0; l < L; l++) {
+          const int64_t v = (int64_t)r[l] + cc;
+          r[l] = (uint32_t)v & LMASK;
+          cc = v >> W;
+        }
+        cin = (int32_t)from_below((uint32_t)(int32_t)cc);
+      }
+    }
+  }
+  // is the exactly-normalised value r >= n ?  (same answer in every lane of the group)
+  __device__ __forceinline__ bool ge_n(const uint32_t (&r)[L]) const {
+    int cmp = 0;
+#pragma unroll
+    for (int l = L - 1; l >= 0; l--) cmp = (cmp != 0) ? cmp : ((r[l] > n[l]) ? 1 : ((r[l] < n[l]) ? -1 : 0));
+    const uint64_t gt = __ballot(cmp > 0), lt = __ballot(cmp < 0);
+    constexpr uint64_t GM = (G == 64) ? ~0ull : ((1ull << G) - 1);
+    const uint32_t ggt = (uint32_t)((gt >> (g * G)) & GM), glt = (uint32_t)((lt >> (g * G)) & GM);
+    return ggt >= glt;  // disjoint bit sets: the more significant differing lane decides; equal -> true
+  }
+  // r (lazy, value < 2^k * n for small k) -> canonical residue in [0, n), exact limbs
+  __device__ __forceinline__ void canonical(uint32_t (&r)[L]) const {
+    uint32_t zero[L];
+#pragma unroll
+    for (int l = 0; l < L; l++) zero[l] = 0;
+    normalize(r, zero);
+    for (int it = 0; it < 4; it++) {
+      const bool ge = ge_n(r);
+      if (!__any(ge)) break;
+      uint32_t sub[L];
+#pragma unroll
+      for (int l = 0; l < L; l++) sub[l] = ge ? n[l] : 0u;
+      normalize(r, sub);
+    }
+  }
+  __device__ __forceinline__ bool equal(const uint32_t (&a)[L], const uint32_t (&b)[L]) const {
+    uint32_t d = 0;
+#pragma unroll
+    for (int l = 0; l < L; l++) d |= a[l] ^ b[l];
+    const uint64_t ne = __ballot(d != 0);
+    constexpr uint64_t GM = (G == 64) ? ~0ull : ((1ull << G) - 1);
+    return ((ne >> (g * G)) & GM) == 0;
+  }
+
+  // -------------------------------------------------------------------------------------------
+  // LDS staging and format conversion (single-wave workgroups: __syncthreads() is a wave barrier)
+  // -------------------------------------------------------------------------------------------
+  __device__ __forceinline__ void stage(uint32_t* dst_lds /*group area*/, const uint32_t (&x)[L]) const {
+#pragma unroll
+    for (int l = 0; l < L; l++) dst_lds[j * L + l] = x[l];
+  }
+  // copy S limbs (limb form, global) of one number into this lane's registers
+  __device__ __forceinline__ void load_limbs(uint32_t (&x)[L], const uint32_t* __restrict__ src) const {
+#pragma unroll
+    for (int l = 0; l < L; l++) x[l] = src[j * L + l];
+  }
+  __device__ __forceinline__ void store_limbs(uint32_t* __restrict__ dst, const uint32_t (&x)[L]) const {
+#pragma unroll
+    for (int l = 0; l < L; l++) dst[j * L + l] = x[l];
+  }
+  // canonical little-endian 32-bit words (global) -> limb form.  wtmp: group's WP-word LDS scratch.
+  // Reads `nwords` words starting at word offset `woff`, i.e. the value floor(x / 2^(32 woff)) mod 2^(32 nwords).
+  __device__ __forceinline__ void load_words(uint32_t (&x)[L], const uint32_t* __restrict__ src, int nwords,
+                                             uint32_t* wtmp) const {
+    __syncthreads();
+    for (int t = j; t < WP; t += G) wtmp[t] = (t < nwords) ? src[t] : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+      const int bit = W * (j * L + l);
+      const int w0 = bit >> 5, sh = bit & 31;
+      const uint64_t v = ((uint64_t)wtmp[w0 + 1] << 32) | wtmp[w0];
+      x[l] = (uint32_t)(v >> sh) & LMASK;
+    }
+  }
+  // exact limbs -> canonical 32-bit words (global).  ltmp: group's SP-limb LDS scratch.
+  __device__ __forceinline__ void store_words(uint32_t* __restrict__ dst, int nwords, const uint32_t (&x)[L],
+                                              uint32_t* ltmp, bool pred) const {
+    __syncthreads();
+    stage(ltmp, x);
+    if (j == 0) { ltmp[S] = 0; ltmp[S + 1] = 0; ltmp[S + 2] = 0; }
+    __syncthreads();
+    if (pred) {
+      for (int t = j; t < nwords; t += G) {
+        const int bit = 32 * t;
+        const int i0 = bit / W, off = bit - i0 * W;
+        uint32_t word = 0;
+        if (i0 < S) {
+          const uint64_t v = (uint64_t)ltmp[i0] | ((uint64_t)ltmp[i0 + 1] << W) | ((uint64_t)ltmp[i0 + 2] << (2 * W));
+          word = (uint32_t)(v >> off);
+        }
+        dst[t] = word;
+      }
+    }
+  }
+};
+
+}  // namespace sc

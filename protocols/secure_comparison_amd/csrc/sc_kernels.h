@@ -1,0 +1,273 @@
+// Device kernels (gfx950).  Included once by sc_lib.hip.
+#pragma once
+#include "sc_device.h"
+#include "sc_vm.h"
+
+namespace sc {
+#ifndef SC_VM_WAVES
+#define SC_VM_WAVES 2
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// The micro-op interpreter.  One 64-lane workgroup (= one wave) processes 64/G items per pass of
+// the program and grid-strides over the batch.
+// ---------------------------------------------------------------------------------------------
+template <int G, int L>
+__global__ void __launch_bounds__(64, SC_VM_WAVES) k_vm(const VmArgs args) {
+  using GT = Grp<G, L>;
+  constexpr int S = GT::S, NG = GT::NG, SP = GT::SP, WP = GT::WP;
+  __shared__ uint32_t s_a[NG * SP];            // per-group staging area for the LDS-side operand
+  __shared__ uint32_t s_w[NG * WP];            // per-group 32-bit-word scratch for format conversion
+  __shared__ uint32_t s_c[VM_MAX_CONST * SP];  // modulus constants shared by all groups
+
+  GT gp;
+  gp.init(args.modctx, args.n0inv);
+  uint32_t* const my_a = s_a + gp.g * SP;
+  uint32_t* const my_w = s_w + gp.g * WP;
+  for (int t = threadIdx.x; t < 2 * S; t += 64) s_c[(t / S) * SP + (t % S)] = args.modctx[S + t];
+  for (int t = threadIdx.x; t < (int)args.nconst_extra * S; t += 64)
+    s_c[(2 + t / S) * SP + (t % S)] = args.consts[t];
+  __syncthreads();
+
+  const uint64_t slot = (uint64_t)blockIdx.x * NG + gp.g;
+  uint32_t* const my_tbl = args.scratch + slot * (uint64_t)args.nscratch * S;
+
+  for (uint64_t base = (uint64_t)blockIdx.x * NG; base < args.count; base += (uint64_t)gridDim.x * NG) {
+    const bool live = base + gp.g < args.count;
+    const uint64_t idx = live ? base + gp.g : args.count - 1;
+    uint32_t acc[L];
+#pragma unroll
+    for (int l = 0; l < L; l++) acc[l] = 0;
+
+#pragma unroll 1
+    for (uint32_t pc = 0; pc < args.nops; pc++) {
+      const VmOp op = args.prog[pc];
+      const uint32_t opc = op.w0 & 0xff, akind = (op.w0 >> 8) & 0xf, imm = op.w0 >> 16;
+
+      // ---- resolve a limb-form / word-form source described by akind (used by MUL and LOADT)
+      const uint32_t* a_ptr = my_a;          // LDS pointer handed to the multiplier
+      const uint32_t* src_limbs = nullptr;   // global limb-form source (copied to registers / LDS)
+      bool src_is_one = false;
+      if (opc == OP_MUL || opc == OP_LOADT) {
+        if (akind == AK_CONST) {
+          a_ptr = s_c + op.w1 * SP;
+        } else if (akind == AK_TBL) {
+          src_limbs = my_tbl + (uint64_t)op.w1 * S;
+        } else if (akind == AK_TBLSEL) {
+          const VmExt& ea = args.ext[op.w1 & 0xf];
+          const VmExt& eb = args.ext[(op.w1 >> 12) & 0xf];
+          const uint64_t fa = ((const uint64_t*)ea.ptr)[idx] >> ((op.w1 >> 4) & 0xff);
+          const uint64_t fb = ((const uint64_t*)eb.ptr)[idx] >> ((op.w1 >> 16) & 0xff);
+          const uint32_t sel = (uint32_t)((fa & 1) * 2 + (fb & 1));
+          src_limbs = my_tbl + (uint64_t)((op.w2 >> (8 * sel)) & 0xff) * S;
+        } else if (akind == AK_TBLDIG || akind == AK_FBT) {
+          const VmExt& e = args.ext[op.w1 & 0xf];
+          const uint32_t bitpos = (op.w1 >> 4) & 0xfffff, width = op.w1 >> 24;
+          const uint32_t* ew = (const uint32_t*)e.ptr + idx * e.stride;
+          const uint32_t w0i = bitpos >> 5, sh = bitpos & 31;
+          uint64_t v = (w0i < e.nwords) ? ew[w0i] : 0u;
+          if (w0i + 1 < e.nwords) v |= (uint64_t)ew[w0i + 1] << 32;
+          const uint32_t digit = (uint32_t)(v >> sh) & ((1u << width) - 1);
+          src_limbs = (akind == AK_TBLDIG) ? my_tbl + (uint64_t)(op.w2 + digit) * S
+                                           : args.fbt + (((uint64_t)op.w2 << width) + digit) * S;
+        } else if (akind == AK_EXTL) {
+          const VmExt& e = args.ext[op.w1 & 0xf];
+          const uint64_t flat = (uint64_t)op.w2 * args.count + idx;
+          if (flat < e.limit) src_limbs = (const uint32_t*)e.ptr + flat * e.stride; else src_is_one = true;
+        }
+      }
+
+      switch (opc) {
+        case OP_MUL: {
+          __syncthreads();
+          if (akind == AK_ACC) {
+            gp.stage(my_a, acc);
+          } else if (akind == AK_EXTW) {
+            const VmExt& e = args.ext[op.w1 & 0xf];
+            const uint64_t flat = (uint64_t)op.w2 * args.count + idx;
+            uint32_t t[L];
+            const bool ok = flat < e.limit;  // may differ per group: keep the barriers in load_words uniform
+            gp.load_words(t, (const uint32_t*)e.ptr + (ok ? flat : 0) * e.stride, e.nwords, my_w);
+#pragma unroll
+            for (int l = 0; l < L; l++) t[l] = ok ? t[l] : ((gp.j == 0 && l == 0) ? 1u : 0u);
+            gp.stage(my_a, t);
+          } else if (src_limbs != nullptr) {
+#pragma unroll
+            for (int l = 0; l < L; l++) my_a[gp.j * L + l] = src_limbs[gp.j * L + l];
+          } else if (src_is_one) {
+            a_ptr = s_c + 1 * SP;  // Montgomery one: multiplying by it is the identity
+          }
+          __syncthreads();
+          uint32_t r[L];
+          gp.mul(r, a_ptr, acc);
+#pragma unroll
+          for (int l = 0; l < L; l++) acc[l] = r[l];
+          break;
+        }
+        case OP_LOADT: {
+          if (akind == AK_CONST || src_is_one) {
+            const uint32_t* c = src_is_one ? s_c + 1 * SP : a_ptr;
+#pragma unroll
+            for (int l = 0; l < L; l++) acc[l] = c[gp.j * L + l];
+          } else {
+            gp.load_limbs(acc, src_limbs);
+          }
+          break;
+        }
+        case OP_LOADW:
+        case OP_ADDW: {
+          const VmExt& e = args.ext[op.w1 & 0xf];
+          const uint64_t flat = (uint64_t)op.w2 * args.count + idx;
+          const uint32_t woff = op.w3 >> 16;
+          const uint32_t nw = (op.w3 & 0xffff) ? (op.w3 & 0xffff) : e.nwords;
+          uint32_t t[L];
+          const bool ok = flat < e.limit;
+          gp.load_words(t, (const uint32_t*)e.ptr + (ok ? flat : 0) * e.stride + woff, nw, my_w);
+#pragma unroll
+          for (int l = 0; l < L; l++) t[l] = ok ? t[l] : ((gp.j == 0 && l == 0) ? 1u : 0u);
+#pragma unroll
+          for (int l = 0; l < L; l++) acc[l] = (opc == OP_LOADW) ? t[l] : acc[l] + t[l];
+          break;
+        }
+        case OP_REDC: {
+          uint32_t r[L];
+          gp.redc(r, acc);
+#pragma unroll
+          for (int l = 0; l < L; l++) acc[l] = r[l];
+          break;
+        }
+        case OP_CANON: {
+          gp.canonical(acc);
+          break;
+        }
+        case OP_STOREW: {
+          gp.canonical(acc);
+          const VmExt& e = args.ext[op.w1 & 0xf];
+          const uint64_t flat = (uint64_t)op.w2 * args.count + idx;
+          gp.store_words((uint32_t*)e.ptr + flat * e.stride, e.nwords, acc, my_a, live && flat < e.limit);
+          break;
+        }
+        case OP_STOREFLAG: {
+          gp.canonical(acc);
+          uint32_t ref[L];
+#pragma unroll
+          for (int l = 0; l < L; l++) ref[l] = s_c[op.w3 * SP + gp.j * L + l];
+          const bool eq = gp.equal(acc, ref);
+          const VmExt& e = args.ext[op.w1 & 0xf];
+          const uint64_t flat = (uint64_t)op.w2 * args.count + idx;
+          if (live && gp.j == 0 && flat < e.limit) ((uint8_t*)e.ptr)[flat] = eq ? 1 : 0;
+          break;
+        }
+        case OP_STT: {
+          gp.store_limbs(my_tbl + (uint64_t)imm * S, acc);
+          break;
+        }
+        case OP_STOREL: {
+          const VmExt& e = args.ext[op.w1 & 0xf];
+          const uint64_t flat = (uint64_t)op.w2 * args.count + idx;
+          if (live && flat < e.limit) gp.store_limbs((uint32_t*)e.ptr + flat * e.stride, acc);
+          break;
+        }
+        case OP_ADD1: {
+          acc[0] += (gp.j == 0) ? 1u : 0u;
+          break;
+        }
+        case OP_SUB1: {
+          uint32_t sub[L];
+#pragma unroll
+          for (int l = 0; l < L; l++) sub[l] = (gp.j == 0 && l == 0) ? 1u : 0u;
+          gp.normalize(acc, sub);
+          break;
+        }
+        case OP_QUOT: {
+          uint32_t r[L], quot[L], zero[L];
+#pragma unroll
+          for (int l = 0; l < L; l++) { quot[l] = 0; zero[l] = 0; }
+          gp.template mont<2>(r, nullptr, acc, quot);
+          // quot = -ACC / n mod R  ->  ACC / n = (R - quot) mod R
+#pragma unroll
+          for (int l = 0; l < L; l++) acc[l] = 0;
+          gp.normalize(acc, quot);
+          (void)zero;
+          break;
+        }
+        default: break;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Plain-integer helper kernels on canonical 32-bit words (HBM-bound, one thread per item).
+// ---------------------------------------------------------------------------------------------
+// Alice's plaintext-side values derived from r (SC/initiator.py:250-256, :270, :289, :373, :558-562):
+//   m1 = 2^l + r (as nw+1 words), alpha = r mod 2^l, alpha_tilde = (r - N) mod 2^l,
+//   rsmall = [r < (N-1)/2], rshift = r >> l.
+__global__ void k_plain_alice(const uint32_t* __restrict__ r, const uint32_t* __restrict__ nmod,
+                              const uint32_t* __restrict__ halfn /* (N-1)/2 */, int nw, int l, uint64_t count,
+                              uint32_t* __restrict__ m1, uint64_t* __restrict__ alpha,
+                              uint64_t* __restrict__ alpha_tilde, uint64_t* __restrict__ rsmall,
+                              uint32_t* __restrict__ rshift) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const uint32_t* ri = r + i * nw;
+  const uint64_t lmask = (l >= 64) ? ~0ull : ((1ull << l) - 1);
+  const uint64_t rlow = (uint64_t)ri[0] | ((nw > 1) ? ((uint64_t)ri[1] << 32) : 0ull);
+  const uint64_t nlow = (uint64_t)nmod[0] | ((nw > 1) ? ((uint64_t)nmod[1] << 32) : 0ull);
+  alpha[i] = rlow & lmask;
+  alpha_tilde[i] = (rlow - nlow) & lmask;
+  int cmp = 0;  // r ? halfn
+  for (int k = nw - 1; k >= 0 && cmp == 0; k--) cmp = (ri[k] > halfn[k]) ? 1 : ((ri[k] < halfn[k]) ? -1 : 0);
+  rsmall[i] = (cmp < 0) ? 1ull : 0ull;
+  // m1 = r + 2^l  (nw + 1 words)
+  uint64_t carry = 0;
+  for (int k = 0; k <= nw; k++) {
+    uint64_t v = (k < nw ? (uint64_t)ri[k] : 0ull) + carry + ((k == (l >> 5)) ? (1ull << (l & 31)) : 0ull);
+    m1[i * (nw + 1) + k] = (uint32_t)v;
+    carry = v >> 32;
+  }
+  // rshift = r >> l
+  const int ws = l >> 5, bs = l & 31;
+  for (int k = 0; k < nw; k++) {
+    const uint64_t lo = (k + ws < nw) ? ri[k + ws] : 0u, hi = (k + ws + 1 < nw) ? ri[k + ws + 1] : 0u;
+    rshift[i * nw + k] = (uint32_t)(((hi << 32) | lo) >> bs);
+  }
+}
+
+// Bob's plaintext-side values derived from z (SC/keyholder.py:196, :213, :274-282):
+//   beta = z mod 2^l, dbit = [z < (N-1)/2], zeta1 = z >> l, zeta2 = (z + N) >> l if dbit else z >> l.
+__global__ void k_plain_bob(const uint32_t* __restrict__ z, const uint32_t* __restrict__ nmod,
+                            const uint32_t* __restrict__ halfn, int nw, int l, uint64_t count,
+                            uint64_t* __restrict__ beta, uint64_t* __restrict__ dbit, uint32_t* __restrict__ zeta1,
+                            uint32_t* __restrict__ zeta2) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const uint32_t* zi = z + i * nw;
+  const uint64_t lmask = (l >= 64) ? ~0ull : ((1ull << l) - 1);
+  const uint64_t zlow = (uint64_t)zi[0] | ((nw > 1) ? ((uint64_t)zi[1] << 32) : 0ull);
+  beta[i] = zlow & lmask;
+  int cmp = 0;
+  for (int k = nw - 1; k >= 0 && cmp == 0; k--) cmp = (zi[k] > halfn[k]) ? 1 : ((zi[k] < halfn[k]) ? -1 : 0);
+  const bool d = cmp < 0;
+  dbit[i] = d ? 1ull : 0ull;
+  const int ws = l >> 5, bs = l & 31;
+  // zeta2: first the sum z + (d ? N : 0) (fits nw words: z < (N-1)/2 when d), then an in-place
+  // ascending funnel shift (word o only reads words >= o).
+  uint32_t* z2 = zeta2 + i * nw;
+  uint64_t carry = 0;
+  for (int k = 0; k < nw; k++) {
+    const uint64_t v = (uint64_t)zi[k] + (d ? nmod[k] : 0u) + carry;
+    z2[k] = (uint32_t)v;
+    carry = v >> 32;
+  }
+  for (int k = 0; k < nw; k++) {
+    const uint64_t lo = (k + ws < nw) ? z2[k + ws] : 0u, hi = (k + ws + 1 < nw) ? z2[k + ws + 1] : 0u;
+    z2[k] = (uint32_t)(((hi << 32) | lo) >> bs);
+  }
+  for (int k = 0; k < nw; k++) {
+    const uint64_t lo = (k + ws < nw) ? zi[k + ws] : 0u, hi = (k + ws + 1 < nw) ? zi[k + ws + 1] : 0u;
+    zeta1[i * nw + k] = (uint32_t)(((hi << 32) | lo) >> bs);
+  }
+}
+
+}  // namespace sc

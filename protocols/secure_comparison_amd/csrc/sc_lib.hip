@@ -1,0 +1,904 @@
+// libsc_amd.so -- host side of the C ABI declared in include/sc_amd.h.
+// Builds the micro-programs (sc_vm.h) for each batched operation and launches the gfx950 kernels.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../../include/sc_amd.h"
+#include "sc_kernels.h"
+#include "sc_xgcd.h"
+
+using namespace sc;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// tiny host big-integer helpers on little-endian uint32 word vectors (setup-time only)
+// ------------------------------------------------------------------------------------------------
+typedef std::vector<uint32_t> Big;
+
+int big_bits(const Big& a) {
+  for (int i = (int)a.size() - 1; i >= 0; i--)
+    if (a[i]) return 32 * i + (32 - __builtin_clz(a[i]));
+  return 0;
+}
+int big_cmp(const Big& a, const Big& b) {  // same length
+  for (int i = (int)a.size() - 1; i >= 0; i--)
+    if (a[i] != b[i]) return a[i] > b[i] ? 1 : -1;
+  return 0;
+}
+void big_sub(Big& a, const Big& b) {  // a -= b, same length
+  uint64_t borrow = 0;
+  for (size_t i = 0; i < a.size(); i++) {
+    uint64_t v = (uint64_t)a[i] - b[i] - borrow;
+    a[i] = (uint32_t)v;
+    borrow = (v >> 32) & 1;
+  }
+}
+// a = 2a mod n  (a < n, a and n have the same length with one spare top word)
+void big_dbl_mod(Big& a, const Big& n) {
+  uint32_t carry = 0;
+  for (size_t i = 0; i < a.size(); i++) {
+    uint32_t nc = a[i] >> 31;
+    a[i] = (a[i] << 1) | carry;
+    carry = nc;
+  }
+  if (big_cmp(a, n) >= 0) big_sub(a, n);
+}
+// x * 2^k mod n
+Big big_shl_mod(const Big& x, const Big& n, int k) {
+  Big nn = n; nn.push_back(0);
+  Big v = x; v.resize(nn.size(), 0);
+  while (big_cmp(v, nn) >= 0) big_sub(v, nn);
+  for (int i = 0; i < k; i++) big_dbl_mod(v, nn);
+  v.resize(n.size());
+  return v;
+}
+std::vector<uint32_t> to_limbs(const Big& x, int S) {
+  std::vector<uint32_t> out(S, 0);
+  for (int i = 0; i < S; i++) {
+    int bit = W * i, w0 = bit >> 5, sh = bit & 31;
+    uint64_t v = (w0 < (int)x.size()) ? x[w0] : 0;
+    if (w0 + 1 < (int)x.size()) v |= (uint64_t)x[w0 + 1] << 32;
+    out[i] = (uint32_t)(v >> sh) & LMASK;
+  }
+  return out;
+}
+
+struct Config { int G, L; };
+const Config kConfigs[] = {{1, 18}, {2, 18}, {2, 27}, {4, 18}, {4, 27}, {8, 18}, {8, 27}, {16, 18}};
+
+struct Mod {
+  int G = 0, L = 0, S = 0, nwords = 0, nbits = 0;
+  Big n;
+  uint32_t n0inv = 0;
+  uint32_t* d_ctx = nullptr;  // n | R^2 | R  limb form
+};
+struct Exp { Big e; int bits = 0; };
+struct Const { int mod = -1; uint32_t* d_limbs = nullptr; };
+struct Fbt { int mod = -1, window = 0, nwin = 0, exp_bits = 0; uint32_t* d_rows = nullptr; };
+struct Prog {
+  uint32_t nops = 0, nscratch = 1, nconst = 0;
+  VmOp* d_ops = nullptr;
+  uint32_t* d_consts = nullptr;
+  double muls_per_item = 0;   // Montgomery products (full) per item
+  double redcs_per_item = 0;  // reduction-only passes per item
+};
+
+}  // namespace
+
+struct sc_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int num_cu = 256;
+  std::string err;
+  std::vector<Mod> mods;
+  std::vector<Exp> exps;
+  std::vector<Const> consts;
+  std::vector<Fbt> fbts;
+  std::map<std::string, Prog> progs;
+  uint32_t* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  std::vector<void*> owned;
+  double mac_counter = 0;
+  std::map<int, int> occ_cache;  // config index -> blocks per CU
+};
+
+namespace {
+
+int fail(sc_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  if (ctx) ctx->err = buf;
+  return code;
+}
+#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(ctx, SC_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
+
+int dev_alloc(sc_ctx* ctx, size_t bytes, void** out) {
+  HIPCHK(ctx, hipMalloc(out, bytes ? bytes : 4));
+  ctx->owned.push_back(*out);
+  return SC_OK;
+}
+int upload(sc_ctx* ctx, const void* h, size_t bytes, void** out) {
+  int rc = dev_alloc(ctx, bytes, out);
+  if (rc) return rc;
+  HIPCHK(ctx, hipMemcpy(*out, h, bytes, hipMemcpyHostToDevice));
+  return SC_OK;
+}
+int ensure_scratch(sc_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->scratch_bytes) return SC_OK;
+  if (ctx->scratch) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->scratch)); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
+  size_t want = bytes + bytes / 4;
+  HIPCHK(ctx, hipMalloc((void**)&ctx->scratch, want));
+  ctx->scratch_bytes = want;
+  return SC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// program builder
+// ------------------------------------------------------------------------------------------------
+struct Builder {
+  std::vector<VmOp> ops;
+  std::vector<int> consts;  // extra constant ids (LDS index = 2 + position)
+  uint32_t nscratch = 1;
+  double muls = 0, redcs = 0;
+  void touch(uint32_t e) { nscratch = std::max(nscratch, e + 1); }
+  void emit(uint32_t opc, uint32_t ak = 0, uint32_t imm = 0, uint32_t w1 = 0, uint32_t w2 = 0, uint32_t w3 = 0) {
+    ops.push_back(VmOp{opc | (ak << 8) | (imm << 16), w1, w2, w3});
+  }
+  int use_const(int cid) {
+    for (size_t i = 0; i < consts.size(); i++) if (consts[i] == cid) return 2 + (int)i;
+    consts.push_back(cid);
+    return 2 + (int)consts.size() - 1;
+  }
+  void mul_const(int lds_idx) { emit(OP_MUL, AK_CONST, 0, lds_idx); muls++; }
+  void sqr() { emit(OP_MUL, AK_ACC); muls++; }
+  void mul_tbl(uint32_t e) { touch(e); emit(OP_MUL, AK_TBL, 0, e); muls++; }
+  void mul_tblsel(int extA, int bitA, int extB, int bitB, uint32_t e00, uint32_t e01, uint32_t e10, uint32_t e11) {
+    touch(std::max(std::max(e00, e01), std::max(e10, e11)));
+    emit(OP_MUL, AK_TBLSEL, 0, extA | (bitA << 4) | (extB << 12) | (bitB << 16), e00 | (e01 << 8) | (e10 << 16) | (e11 << 24));
+    muls++;
+  }
+  void mul_tbldig(int ext, uint32_t bitpos, uint32_t width, uint32_t base) {
+    touch(base + (1u << width) - 1);
+    emit(OP_MUL, AK_TBLDIG, 0, ext | (bitpos << 4) | (width << 24), base); muls++;
+  }
+  void mul_fbt(int ext, uint32_t bitpos, uint32_t width, uint32_t win) { emit(OP_MUL, AK_FBT, 0, ext | (bitpos << 4) | (width << 24), win); muls++; }
+  void mul_extw(int ext, uint32_t off = 0) { emit(OP_MUL, AK_EXTW, 0, ext, off); muls++; }
+  void mul_extl(int ext, uint32_t off = 0) { emit(OP_MUL, AK_EXTL, 0, ext, off); muls++; }
+  void loadw(int ext, uint32_t off = 0, uint32_t woff = 0, uint32_t nw = 0) { emit(OP_LOADW, 0, 0, ext, off, (woff << 16) | nw); }
+  void addw(int ext, uint32_t off = 0, uint32_t woff = 0, uint32_t nw = 0) { emit(OP_ADDW, 0, 0, ext, off, (woff << 16) | nw); }
+  void loadt_const(int lds_idx) { emit(OP_LOADT, AK_CONST, 0, lds_idx); }
+  void loadt_tbl(uint32_t e) { touch(e); emit(OP_LOADT, AK_TBL, 0, e); }
+  void loadt_tbldig(int ext, uint32_t bitpos, uint32_t width, uint32_t base) {
+    touch(base + (1u << width) - 1);
+    emit(OP_LOADT, AK_TBLDIG, 0, ext | (bitpos << 4) | (width << 24), base);
+  }
+  void loadt_tblsel(int extA, int bitA, int extB, int bitB, uint32_t e00, uint32_t e01, uint32_t e10, uint32_t e11) {
+    touch(std::max(std::max(e00, e01), std::max(e10, e11)));
+    emit(OP_LOADT, AK_TBLSEL, 0, extA | (bitA << 4) | (extB << 12) | (bitB << 16), e00 | (e01 << 8) | (e10 << 16) | (e11 << 24));
+  }
+  void loadt_fbt(int ext, uint32_t bitpos, uint32_t width, uint32_t win) { emit(OP_LOADT, AK_FBT, 0, ext | (bitpos << 4) | (width << 24), win); }
+  void loadt_extl(int ext, uint32_t off = 0) { emit(OP_LOADT, AK_EXTL, 0, ext, off); }
+  void stt(uint32_t e) { touch(e); emit(OP_STT, 0, e); }
+  void redc() { emit(OP_REDC); redcs++; }
+  void storew(int ext, uint32_t off = 0) { emit(OP_STOREW, 0, 0, ext, off); }
+  void storel(int ext, uint32_t off = 0) { emit(OP_STOREL, 0, 0, ext, off); }
+  void storeflag(int ext, uint32_t off, int lds_const) { emit(OP_STOREFLAG, 0, 0, ext, off, lds_const); }
+  void end() { emit(OP_END); }
+};
+
+int finalize_prog(sc_ctx* ctx, const Mod& m, Builder& b, Prog* out) {
+  if (b.consts.size() + 2 > VM_MAX_CONST) return fail(ctx, SC_ERR_ARG, "too many constants in program");
+  Prog p;
+  p.nops = (uint32_t)b.ops.size();
+  p.nscratch = b.nscratch;
+  p.nconst = (uint32_t)b.consts.size();
+  p.muls_per_item = b.muls;
+  p.redcs_per_item = b.redcs;
+  int rc = upload(ctx, b.ops.data(), b.ops.size() * sizeof(VmOp), (void**)&p.d_ops);
+  if (rc) return rc;
+  if (p.nconst) {
+    rc = dev_alloc(ctx, (size_t)p.nconst * m.S * 4, (void**)&p.d_consts);
+    if (rc) return rc;
+    for (uint32_t i = 0; i < p.nconst; i++)
+      HIPCHK(ctx, hipMemcpy(p.d_consts + (size_t)i * m.S, ctx->consts[b.consts[i]].d_limbs, (size_t)m.S * 4, hipMemcpyDeviceToDevice));
+  }
+  *out = p;
+  return SC_OK;
+}
+
+template <int G, int L>
+int launch_vm_cfg(sc_ctx* ctx, const VmArgs& a, int cfg_index) {
+  auto it = ctx->occ_cache.find(cfg_index);
+  int occ;
+  if (it == ctx->occ_cache.end()) {
+    int nb = 0;
+    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_vm<G, L>, 64, 0));
+    occ = std::max(1, std::min(nb, 16));
+    ctx->occ_cache[cfg_index] = occ;
+  } else {
+    occ = it->second;
+  }
+  constexpr int NG = 64 / G;
+  uint64_t need = (a.count + NG - 1) / NG;
+  uint64_t maxb = (uint64_t)ctx->num_cu * occ;
+  uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min(need, maxb));
+  size_t scratch_bytes = (size_t)grid * NG * a.nscratch * (G * L) * 4;
+  int rc = ensure_scratch(ctx, scratch_bytes);
+  if (rc) return rc;
+  VmArgs args = a;
+  args.scratch = ctx->scratch;
+  hipLaunchKernelGGL((k_vm<G, L>), dim3(grid), dim3(64), 0, ctx->stream, args);
+  HIPCHK(ctx, hipGetLastError());
+  return SC_OK;
+}
+
+int run_vm(sc_ctx* ctx, int mod, const Prog& p, const VmExt* exts, int next, uint64_t count, const uint32_t* fbt_rows = nullptr) {
+  if (count == 0) return SC_OK;
+  const Mod& m = ctx->mods[mod];
+  VmArgs a;
+  memset(&a, 0, sizeof a);
+  a.modctx = m.d_ctx;
+  a.consts = p.d_consts;
+  a.prog = p.d_ops;
+  a.fbt = fbt_rows;
+  a.count = count;
+  a.n0inv = m.n0inv;
+  a.nops = p.nops;
+  a.nconst_extra = p.nconst;
+  a.nscratch = p.nscratch;
+  for (int i = 0; i < next; i++) a.ext[i] = exts[i];
+  ctx->mac_counter += (double)count * (p.muls_per_item * 2.0 + p.redcs_per_item) * (double)m.S * m.S;
+  int rc = SC_ERR_UNSUPPORTED;
+  int ci = 0;
+#define SC_CASE(GG, LL) if (m.G == GG && m.L == LL) rc = launch_vm_cfg<GG, LL>(ctx, a, ci); ci++;
+  SC_CASE(1, 18) SC_CASE(2, 18) SC_CASE(2, 27) SC_CASE(4, 18) SC_CASE(4, 27) SC_CASE(8, 18) SC_CASE(8, 27) SC_CASE(16, 18)
+#undef SC_CASE
+  if (rc == SC_ERR_UNSUPPORTED) return fail(ctx, rc, "no kernel configuration for G=%d L=%d", m.G, m.L);
+  return rc;
+}
+
+VmExt mk_ext(const void* p, uint32_t stride, uint32_t nwords, uint64_t limit = ~0ull) {
+  VmExt e; e.ptr = p; e.stride = stride; e.nwords = nwords; e.limit = limit; return e;
+}
+
+bool valid_mod(sc_ctx* ctx, int mod) { return ctx && mod >= 0 && mod < (int)ctx->mods.size(); }
+
+// emit: ACC = (ext value reduced mod n), for an operand of x_words >= mod words (Horner over chunks)
+void emit_load_reduced(sc_ctx* ctx, const Mod& m, Builder& b, int ext, int x_words, int kred_lds) {
+  const int cw = m.nwords;
+  const int nch = (x_words + cw - 1) / cw;
+  for (int t = nch - 1; t >= 0; t--) {
+    const int nw = std::min(cw, x_words - t * cw);
+    if (t == nch - 1) {
+      b.loadw(ext, 0, t * cw, nw);
+    } else {
+      b.mul_const(kred_lds);          // ACC *= 2^(32 cw)   (kred is Montgomery form of that power)
+      b.addw(ext, 0, t * cw, nw);
+    }
+  }
+  (void)ctx;
+}
+
+int best_window(int bits) {
+  int best = 1; double bc = 1e30;
+  for (int w = 1; w <= 6; w++) {
+    double c = (double)(1 << (w - 1)) + (double)bits / (w + 1);
+    if (c < bc) { bc = c; best = w; }
+  }
+  return best;
+}
+inline int ebit(const Big& e, int i) { return (e[i >> 5] >> (i & 31)) & 1; }
+
+// emit sliding-window exponentiation of the Montgomery-form value currently in ACC; leaves ACC = x^e (Montgomery form)
+void emit_pow_shared(Builder& b, const Exp& ex) {
+  const int bits = ex.bits;
+  if (bits == 0) { b.loadt_const(1); return; }
+  const int w = best_window(bits);
+  const int NT = 1 << (w - 1);            // odd powers x^1, x^3, ..
+  b.stt(0);
+  if (NT > 1) {
+    b.sqr(); b.stt(NT);                   // x^2
+    for (int k = 1; k < NT; k++) { b.loadt_tbl(k - 1); b.mul_tbl(NT); b.stt(k); }
+  }
+  bool first = true;
+  int i = bits - 1;
+  while (i >= 0) {
+    if (!ebit(ex.e, i)) { b.sqr(); i--; continue; }
+    int j = std::max(0, i - w + 1);
+    while (!ebit(ex.e, j)) j++;
+    int v = 0;
+    for (int k = i; k >= j; k--) v = (v << 1) | ebit(ex.e, k);
+    if (first) { b.loadt_tbl((v - 1) / 2); first = false; }
+    else { for (int k = 0; k < i - j + 1; k++) b.sqr(); b.mul_tbl((v - 1) / 2); }
+    i = j - 1;
+  }
+}
+
+int get_const_kred(sc_ctx* ctx, int mod, int* out_cid);
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int sc_abi_version(void) { return 1; }
+
+int sc_ctx_create(int device_id, sc_ctx** out_ctx) {
+  if (!out_ctx) return SC_ERR_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return SC_ERR_HIP;
+  if (hipSetDevice(device_id) != hipSuccess) return SC_ERR_HIP;
+  sc_ctx* c = new sc_ctx();
+  c->device = device_id;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+  *out_ctx = c;
+  return SC_OK;
+}
+
+void sc_ctx_destroy(sc_ctx* ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  hipDeviceSynchronize();
+  for (void* p : ctx->owned) hipFree(p);
+  if (ctx->scratch) hipFree(ctx->scratch);
+  delete ctx;
+}
+
+int sc_ctx_set_stream(sc_ctx* ctx, void* hip_stream) { if (!ctx) return SC_ERR_ARG; ctx->stream = (hipStream_t)hip_stream; return SC_OK; }
+int sc_ctx_synchronize(sc_ctx* ctx) { if (!ctx) return SC_ERR_ARG; HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); return SC_OK; }
+const char* sc_last_error(sc_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int sc_malloc(sc_ctx* ctx, size_t bytes, void** out_dptr) { if (!ctx || !out_dptr) return SC_ERR_ARG; HIPCHK(ctx, hipMalloc(out_dptr, bytes ? bytes : 4)); return SC_OK; }
+int sc_free(sc_ctx* ctx, void* dptr) { if (!ctx) return SC_ERR_ARG; HIPCHK(ctx, hipFree(dptr)); return SC_OK; }
+int sc_memcpy_h2d(sc_ctx* ctx, void* dptr, const void* hptr, size_t bytes) {
+  if (!ctx) return SC_ERR_ARG;
+  HIPCHK(ctx, hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return SC_OK;
+}
+int sc_memcpy_d2h(sc_ctx* ctx, void* hptr, const void* dptr, size_t bytes) {
+  if (!ctx) return SC_ERR_ARG;
+  HIPCHK(ctx, hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return SC_OK;
+}
+
+int sc_mod_create(sc_ctx* ctx, const uint32_t* n_hptr, int nwords, int* out_mod) {
+  if (!ctx || !n_hptr || nwords <= 0 || !out_mod) return fail(ctx, SC_ERR_ARG, "sc_mod_create: bad argument");
+  Mod m;
+  m.n.assign(n_hptr, n_hptr + nwords);
+  m.nwords = nwords;
+  m.nbits = big_bits(m.n);
+  if (m.nbits < 2 || !(m.n[0] & 1)) return fail(ctx, SC_ERR_ARG, "sc_mod_create: modulus must be odd and > 1");
+  for (const Config& c : kConfigs)
+    if (W * c.G * c.L >= m.nbits + 8 && W * c.G * c.L >= 32 * nwords) { m.G = c.G; m.L = c.L; break; }
+  if (!m.G) {
+    for (const Config& c : kConfigs) if (W * c.G * c.L >= m.nbits + 8) { m.G = c.G; m.L = c.L; break; }
+  }
+  if (!m.G) return fail(ctx, SC_ERR_UNSUPPORTED, "sc_mod_create: %d-bit modulus exceeds the largest configuration", m.nbits);
+  m.S = m.G * m.L;
+  // the residue arrays must be representable below R = 2^(29 S)
+  if (32 * nwords > W * m.S + 31) return fail(ctx, SC_ERR_ARG, "sc_mod_create: nwords=%d too wide for a %d-bit modulus", nwords, m.nbits);
+  // n0inv = -n^-1 mod 2^29 (Newton)
+  uint32_t n0 = m.n[0], inv = 1;
+  for (int i = 0; i < 6; i++) inv *= 2 - n0 * inv;
+  m.n0inv = (0u - inv) & LMASK;
+  Big one(nwords, 0); one[0] = 1;
+  Big r1 = big_shl_mod(one, m.n, W * m.S);
+  Big r2 = big_shl_mod(r1, m.n, W * m.S);
+  std::vector<uint32_t> ctxv;
+  auto app = [&](const Big& x) { auto l = to_limbs(x, m.S); ctxv.insert(ctxv.end(), l.begin(), l.end()); };
+  app(m.n); app(r2); app(r1);
+  int rc = upload(ctx, ctxv.data(), ctxv.size() * 4, (void**)&m.d_ctx);
+  if (rc) return rc;
+  ctx->mods.push_back(m);
+  *out_mod = (int)ctx->mods.size() - 1;
+  return SC_OK;
+}
+
+int sc_mod_words(sc_ctx* ctx, int mod) { return valid_mod(ctx, mod) ? ctx->mods[mod].nwords : SC_ERR_ARG; }
+
+int sc_exp_create(sc_ctx* ctx, const uint32_t* e_hptr, int ewords, int* out_exp) {
+  if (!ctx || !e_hptr || ewords <= 0 || !out_exp) return fail(ctx, SC_ERR_ARG, "sc_exp_create: bad argument");
+  Exp e; e.e.assign(e_hptr, e_hptr + ewords); e.bits = big_bits(e.e);
+  ctx->exps.push_back(e);
+  *out_exp = (int)ctx->exps.size() - 1;
+  return SC_OK;
+}
+
+int sc_const_create(sc_ctx* ctx, int mod, const uint32_t* v_hptr, int nwords, int* out_const) {
+  if (!valid_mod(ctx, mod) || !v_hptr || !out_const) return fail(ctx, SC_ERR_ARG, "sc_const_create: bad argument");
+  const Mod& m = ctx->mods[mod];
+  Big v(v_hptr, v_hptr + nwords);
+  v.resize(std::max(nwords, m.nwords), 0);
+  Big nn = m.n; nn.resize(v.size(), 0);
+  Big vm = big_shl_mod(v, nn, W * m.S);  // Montgomery form
+  auto l = to_limbs(vm, m.S);
+  Const c; c.mod = mod;
+  int rc = upload(ctx, l.data(), l.size() * 4, (void**)&c.d_limbs);
+  if (rc) return rc;
+  ctx->consts.push_back(c);
+  *out_const = (int)ctx->consts.size() - 1;
+  return SC_OK;
+}
+
+}  // extern "C"
+
+namespace {
+// Montgomery form of 2^(32 * nwords): multiplying by it shifts a residue up by one operand width
+int get_const_kred(sc_ctx* ctx, int mod, int* out_cid) {
+  const Mod& m = ctx->mods[mod];
+  std::string key = "kred:" + std::to_string(mod);
+  static std::map<std::pair<sc_ctx*, int>, int> cache;
+  auto it = cache.find({ctx, mod});
+  if (it != cache.end()) { *out_cid = it->second; return SC_OK; }
+  Big one(m.nwords, 0); one[0] = 1;
+  Big v = big_shl_mod(one, m.n, 32 * m.nwords);
+  int cid;
+  int rc = sc_const_create(ctx, mod, v.data(), m.nwords, &cid);
+  if (rc) return rc;
+  cache[{ctx, mod}] = cid;
+  *out_cid = cid;
+  return SC_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int sc_modmul(sc_ctx* ctx, int mod, const uint32_t* a, int a_stride, const uint32_t* b, int b_stride, uint32_t* out, uint64_t count) {
+  if (!valid_mod(ctx, mod) || !a || !b || !out) return fail(ctx, SC_ERR_ARG, "sc_modmul: bad argument");
+  const Mod& m = ctx->mods[mod];
+  std::string key = "modmul:" + std::to_string(mod);
+  auto it = ctx->progs.find(key);
+  if (it == ctx->progs.end()) {
+    Builder bd;
+    bd.loadw(0); bd.mul_const(0);      // a * R
+    bd.mul_extw(1);                    // (aR) * b / R = a b
+    bd.storew(2); bd.end();
+    Prog p; int rc = finalize_prog(ctx, m, bd, &p); if (rc) return rc;
+    it = ctx->progs.emplace(key, p).first;
+  }
+  VmExt ex[3] = {mk_ext(a, a_stride, m.nwords), mk_ext(b, b_stride, m.nwords), mk_ext(out, m.nwords, m.nwords)};
+  return run_vm(ctx, mod, it->second, ex, 3, count);
+}
+
+int sc_modmul_const(sc_ctx* ctx, int mod, const uint32_t* a, int cst, uint32_t* out, uint64_t count) {
+  if (!valid_mod(ctx, mod) || !a || !out || cst < 0 || cst >= (int)ctx->consts.size() || ctx->consts[cst].mod != mod)
+    return fail(ctx, SC_ERR_ARG, "sc_modmul_const: bad argument");
+  const Mod& m = ctx->mods[mod];
+  std::string key = "modmulc:" + std::to_string(mod) + ":" + std::to_string(cst);
+  auto it = ctx->progs.find(key);
+  if (it == ctx->progs.end()) {
+    Builder bd;
+    int c = bd.use_const(cst);
+    bd.loadw(0); bd.mul_const(c);      // a * (cR) / R = a c
+    bd.storew(1); bd.end();
+    Prog p; int rc = finalize_prog(ctx, m, bd, &p); if (rc) return rc;
+    it = ctx->progs.emplace(key, p).first;
+  }
+  VmExt ex[2] = {mk_ext(a, m.nwords, m.nwords), mk_ext(out, m.nwords, m.nwords)};
+  return run_vm(ctx, mod, it->second, ex, 2, count);
+}
+
+static int modexp_shared_impl(sc_ctx* ctx, int mod, int exp, const uint32_t* x, int x_words, const uint32_t* mul_into,
+                              uint32_t* out, uint8_t* flags, uint64_t count) {
+  if (!valid_mod(ctx, mod) || exp < 0 || exp >= (int)ctx->exps.size() || !x || (!out && !flags))
+    return fail(ctx, SC_ERR_ARG, "sc_modexp_shared: bad argument");
+  const Mod& m = ctx->mods[mod];
+  if (x_words <= 0) x_words = m.nwords;
+  const int mode = flags ? 2 : (mul_into ? 1 : 0);
+  std::string key = "mexp:" + std::to_string(mod) + ":" + std::to_string(exp) + ":" + std::to_string(x_words) + ":" + std::to_string(mode);
+  auto it = ctx->progs.find(key);
+  if (it == ctx->progs.end()) {
+    Builder bd;
+    if (x_words > m.nwords) {
+      int kc; int rc = get_const_kred(ctx, mod, &kc); if (rc) return rc;
+      emit_load_reduced(ctx, m, bd, 0, x_words, bd.use_const(kc));
+    } else {
+      bd.loadw(0, 0, 0, x_words);
+    }
+    bd.mul_const(0);                   // to Montgomery form
+    emit_pow_shared(bd, ctx->exps[exp]);
+    if (mode == 0) { bd.redc(); bd.storew(1); }
+    else if (mode == 1) { bd.mul_extw(2); bd.storew(1); }
+    else { bd.storeflag(1, 0, 1); }    // compare with R mod n (Montgomery one)
+    bd.end();
+    Prog p; int rc = finalize_prog(ctx, m, bd, &p); if (rc) return rc;
+    it = ctx->progs.emplace(key, p).first;
+  }
+  VmExt ex[3] = {mk_ext(x, x_words, x_words), flags ? mk_ext(flags, 0, 0) : mk_ext(out, m.nwords, m.nwords),
+                 mk_ext(mul_into, m.nwords, m.nwords)};
+  return run_vm(ctx, mod, it->second, ex, 3, count);
+}
+
+int sc_modexp_shared(sc_ctx* ctx, int mod, int exp, const uint32_t* x, int x_words, const uint32_t* mul_into, uint32_t* out, uint64_t count) {
+  return modexp_shared_impl(ctx, mod, exp, x, x_words, mul_into, out, nullptr, count);
+}
+int sc_modexp_shared_isone(sc_ctx* ctx, int mod, int exp, const uint32_t* x, int x_words, uint8_t* flags, uint64_t count) {
+  return modexp_shared_impl(ctx, mod, exp, x, x_words, nullptr, nullptr, flags, count);
+}
+
+int sc_fbt_create(sc_ctx* ctx, int mod, const uint32_t* base_hptr, int exp_bits, int window, int* out_fbt) {
+  if (!valid_mod(ctx, mod) || !base_hptr || exp_bits <= 0 || window < 1 || window > 20 || !out_fbt)
+    return fail(ctx, SC_ERR_ARG, "sc_fbt_create: bad argument");
+  const Mod& m = ctx->mods[mod];
+  Fbt f; f.mod = mod; f.window = window; f.exp_bits = exp_bits; f.nwin = (exp_bits + window - 1) / window;
+  const uint64_t rows = (uint64_t)f.nwin << window;
+  int rc = dev_alloc(ctx, rows * m.S * 4, (void**)&f.d_rows); if (rc) return rc;
+  int cbase; rc = sc_const_create(ctx, mod, base_hptr, m.nwords, &cbase); if (rc) return rc;
+  // stage A: B_j = base^(2^(window j)), limb form, one item
+  uint32_t* d_B; rc = dev_alloc(ctx, (size_t)f.nwin * m.S * 4, (void**)&d_B); if (rc) return rc;
+  {
+    Builder bd; int c = bd.use_const(cbase);
+    bd.loadt_const(c); bd.storel(0, 0);
+    for (int j = 1; j < f.nwin; j++) { for (int k = 0; k < window; k++) bd.sqr(); bd.storel(0, j); }
+    bd.end();
+    Prog p; rc = finalize_prog(ctx, m, bd, &p); if (rc) return rc;
+    VmExt ex[1] = {mk_ext(d_B, m.S, 0)};
+    rc = run_vm(ctx, mod, p, ex, 1, 1); if (rc) return rc;
+  }
+  // stage B: per window, item ch computes rows d = ch, ch + NCH, ... (start B^ch, step B^NCH)
+  const int lg = std::min(window, 10);
+  const uint32_t NCH = 1u << lg, CH = (1u << window) / NCH;
+  std::vector<uint32_t> idx(NCH); for (uint32_t i = 0; i < NCH; i++) idx[i] = i;
+  uint32_t* d_idx; rc = upload(ctx, idx.data(), NCH * 4, (void**)&d_idx); if (rc) return rc;
+  {
+    Builder bd;
+    bd.loadt_extl(0); bd.stt(1);            // t[1] = B_j
+    bd.loadt_const(1); bd.stt(0);           // t[0] = one
+    bd.loadt_tbl(1); for (int k = 0; k < lg; k++) bd.sqr(); bd.stt(2);   // t[2] = B_j^NCH
+    bd.loadt_tbldig(1, lg - 1, 1, 0);       // B_j^ch by square-and-multiply over the bits of ch
+    for (int k = lg - 2; k >= 0; k--) { bd.sqr(); bd.mul_tbldig(1, k, 1, 0); }
+    bd.storel(2, 0);
+    for (uint32_t i = 1; i < CH; i++) { bd.mul_tbl(2); bd.storel(2, i); }
+    bd.end();
+    Prog p; rc = finalize_prog(ctx, m, bd, &p); if (rc) return rc;
+    for (int j = 0; j < f.nwin; j++) {
+      VmExt ex[3] = {mk_ext(d_B + (size_t)j * m.S, 0, 0), mk_ext(d_idx, 1, 1),
+                     mk_ext(f.d_rows + ((uint64_t)j << window) * m.S, m.S, 0)};
+      rc = run_vm(ctx, mod, p, ex, 3, NCH); if (rc) return rc;
+    }
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->fbts.push_back(f);
+  *out_fbt = (int)ctx->fbts.size() - 1;
+  return SC_OK;
+}
+
+int sc_fixedbase_pow(sc_ctx* ctx, int fbt, const uint32_t* e, int ewords, const uint32_t* mul_into, uint32_t* out, uint64_t count) {
+  if (!ctx || fbt < 0 || fbt >= (int)ctx->fbts.size() || !e || !out || ewords <= 0) return fail(ctx, SC_ERR_ARG, "sc_fixedbase_pow: bad argument");
+  const Fbt& f = ctx->fbts[fbt];
+  const Mod& m = ctx->mods[f.mod];
+  if (32 * ewords < f.exp_bits - 31 && false) return SC_ERR_ARG;
+  std::string key = "fbp:" + std::to_string(fbt) + ":" + std::to_string(mul_into ? 1 : 0);
+  auto it = ctx->progs.find(key);
+  if (it == ctx->progs.end()) {
+    Builder bd;
+    bd.loadt_fbt(0, 0, f.window, 0);
+    for (int j = 1; j < f.nwin; j++) bd.mul_fbt(0, j * f.window, f.window, j);
+    if (mul_into) bd.mul_extw(2); else bd.redc();
+    bd.storew(1); bd.end();
+    Prog p; int rc = finalize_prog(ctx, m, bd, &p); if (rc) return rc;
+    it = ctx->progs.emplace(key, p).first;
+  }
+  VmExt ex[3] = {mk_ext(e, ewords, ewords), mk_ext(out, m.nwords, m.nwords), mk_ext(mul_into, m.nwords, m.nwords)};
+  return run_vm(ctx, f.mod, it->second, ex, 3, count, f.d_rows);
+}
+
+int sc_modexp_var(sc_ctx* ctx, int mod, const uint32_t* x, const uint32_t* e, int ewords, int ebits, int fbt,
+                  const uint32_t* e2, int e2words, uint32_t* out, uint64_t count) {
+  if (!valid_mod(ctx, mod) || !x || !e || !out || ewords <= 0 || ebits <= 0 || ebits > 32 * ewords)
+    return fail(ctx, SC_ERR_ARG, "sc_modexp_var: bad argument");
+  const Mod& m = ctx->mods[mod];
+  const Fbt* f = nullptr;
+  if (fbt >= 0) {
+    if (fbt >= (int)ctx->fbts.size() || ctx->fbts[fbt].mod != mod || !e2 || e2words <= 0) return fail(ctx, SC_ERR_ARG, "sc_modexp_var: bad fixed-base table");
+    f = &ctx->fbts[fbt];
+  }
+  std::string key = "mvar:" + std::to_string(mod) + ":" + std::to_string(ebits) + ":" + std::to_string(fbt);
+  auto it = ctx->progs.find(key);
+  if (it == ctx->progs.end()) {
+    const int w = ebits <= 4 ? 1 : (ebits <= 12 ? 2 : 3);
+    const int nd = (ebits + w - 1) / w;
+    Builder bd;
+    bd.loadw(0); bd.mul_const(0); bd.stt(1);          // t[1] = x (Montgomery)
+    bd.loadt_const(1); bd.stt(0);                      // t[0] = 1
+    for (int k = 2; k < (1 << w); k++) { bd.loadt_tbl(k - 1); bd.mul_tbl(1); bd.stt(k); }
+    bd.loadt_tbldig(1, (nd - 1) * w, w, 0);
+    for (int d = nd - 2; d >= 0; d--) { for (int k = 0; k < w; k++) bd.sqr(); bd.mul_tbldig(1, d * w, w, 0); }
+    if (f) for (int j = 0; j < f->nwin; j++) bd.mul_fbt(3, j * f->window, f->window, j);
+    bd.redc(); bd.storew(2); bd.end();
+    Prog p; int rc = finalize_prog(ctx, m, bd, &p); if (rc) return rc;
+    it = ctx->progs.emplace(key, p).first;
+  }
+  VmExt ex[4] = {mk_ext(x, m.nwords, m.nwords), mk_ext(e, ewords, ewords), mk_ext(out, m.nwords, m.nwords),
+                 mk_ext(e2, e2words, e2words)};
+  return run_vm(ctx, mod, it->second, ex, 4, count, f ? f->d_rows : nullptr);
+}
+
+int sc_paillier_encrypt_raw(sc_ctx* ctx, int mod_n2, int cst_n, const uint32_t* mwords, int m_words, uint32_t* out, uint64_t count) {
+  if (!valid_mod(ctx, mod_n2) || cst_n < 0 || cst_n >= (int)ctx->consts.size() || ctx->consts[cst_n].mod != mod_n2 || !mwords || !out || m_words <= 0)
+    return fail(ctx, SC_ERR_ARG, "sc_paillier_encrypt_raw: bad argument");
+  const Mod& m = ctx->mods[mod_n2];
+  if (m_words > m.nwords) return fail(ctx, SC_ERR_ARG, "sc_paillier_encrypt_raw: plaintext wider than N^2");
+  std::string key = "penc:" + std::to_string(mod_n2) + ":" + std::to_string(cst_n) + ":" + std::to_string(m_words);
+  auto it = ctx->progs.find(key);
+  if (it == ctx->progs.end()) {
+    Builder bd; int c = bd.use_const(cst_n);
+    bd.loadw(0, 0, 0, m_words); bd.mul_const(c);   // m * (N R) / R = m N  (mod N^2)
+    bd.emit(OP_ADD1); bd.storew(1); bd.end();
+    Prog p; int rc = finalize_prog(ctx, m, bd, &p); if (rc) return rc;
+    it = ctx->progs.emplace(key, p).first;
+  }
+  VmExt ex[2] = {mk_ext(mwords, m_words, m_words), mk_ext(out, m.nwords, m.nwords)};
+  return run_vm(ctx, mod_n2, it->second, ex, 2, count);
+}
+
+int sc_paillier_l_mul(sc_ctx* ctx, int mod, int cst_k, const uint32_t* x, int x_words, uint32_t* out, uint64_t count) {
+  if (!valid_mod(ctx, mod) || cst_k < 0 || cst_k >= (int)ctx->consts.size() || ctx->consts[cst_k].mod != mod || !x || !out || x_words <= 0)
+    return fail(ctx, SC_ERR_ARG, "sc_paillier_l_mul: bad argument");
+  const Mod& m = ctx->mods[mod];
+  std::string key = "plmul:" + std::to_string(mod) + ":" + std::to_string(cst_k) + ":" + std::to_string(x_words);
+  auto it = ctx->progs.find(key);
+  if (it == ctx->progs.end()) {
+    Builder bd; int c = bd.use_const(cst_k);
+    const int lw = std::min(x_words, (W * m.S + 31) / 32);   // only x mod R matters for the exact quotient
+    bd.loadw(0, 0, 0, lw);
+    bd.emit(OP_SUB1);                 // y = (x - 1) mod R, exact limbs
+    bd.emit(OP_QUOT); bd.redcs++;     // y / n  (< n because x < n^2)
+    bd.mul_const(c);                  // * k
+    bd.storew(1); bd.end();
+    Prog p; int rc = finalize_prog(ctx, m, bd, &p); if (rc) return rc;
+    it = ctx->progs.emplace(key, p).first;
+  }
+  VmExt ex[2] = {mk_ext(x, x_words, x_words), mk_ext(out, m.nwords, m.nwords)};
+  return run_vm(ctx, mod, it->second, ex, 2, count);
+}
+
+int sc_plain_alice(sc_ctx* ctx, const uint32_t* r, const uint32_t* n_hptr, int nw, int l, uint64_t count, uint32_t* m1,
+                   uint64_t* alpha, uint64_t* alpha_tilde, uint64_t* rsmall, uint32_t* rshift) {
+  if (!ctx || !r || !n_hptr || nw <= 0 || l <= 0 || l > 64 || !m1 || !alpha || !alpha_tilde || !rsmall || !rshift)
+    return fail(ctx, SC_ERR_ARG, "sc_plain_alice: bad argument");
+  if (count == 0) return SC_OK;
+  Big n(n_hptr, n_hptr + nw), half(nw);
+  for (int k = 0; k < nw; k++) half[k] = (n[k] >> 1) | ((k + 1 < nw) ? (n[k + 1] << 31) : 0u);  // (N-1)/2 for odd N
+  uint32_t *d_n, *d_h;
+  HIPCHK(ctx, hipMalloc((void**)&d_n, nw * 8)); d_h = d_n + nw;
+  HIPCHK(ctx, hipMemcpyAsync(d_n, n.data(), nw * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(d_h, half.data(), nw * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_plain_alice, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, r, d_n, d_h, nw, l, count, m1, alpha, alpha_tilde, rsmall, rshift);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipFree(d_n));
+  return SC_OK;
+}
+
+int sc_plain_bob(sc_ctx* ctx, const uint32_t* z, const uint32_t* n_hptr, int nw, int l, uint64_t count, uint64_t* beta,
+                 uint64_t* dbit, uint32_t* zeta1, uint32_t* zeta2) {
+  if (!ctx || !z || !n_hptr || nw <= 0 || l <= 0 || l > 64 || !beta || !dbit || !zeta1 || !zeta2)
+    return fail(ctx, SC_ERR_ARG, "sc_plain_bob: bad argument");
+  if (count == 0) return SC_OK;
+  Big n(n_hptr, n_hptr + nw), half(nw);
+  for (int k = 0; k < nw; k++) half[k] = (n[k] >> 1) | ((k + 1 < nw) ? (n[k + 1] << 31) : 0u);
+  uint32_t *d_n, *d_h;
+  HIPCHK(ctx, hipMalloc((void**)&d_n, nw * 8)); d_h = d_n + nw;
+  HIPCHK(ctx, hipMemcpyAsync(d_n, n.data(), nw * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(d_h, half.data(), nw * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_plain_bob, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, z, d_n, d_h, nw, l, count, beta, dbit, zeta1, zeta2);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipFree(d_n));
+  return SC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// batch inversion: Montgomery's trick over strided chunks + on-device binary extended GCD at the top
+// ------------------------------------------------------------------------------------------------
+static int modinv_rec(sc_ctx* ctx, int mod, const uint32_t* x, uint32_t* out, uint64_t count, int64_t* bad, int depth) {
+  const Mod& m = ctx->mods[mod];
+  const uint64_t TOP = 48;
+  if (count <= TOP) {
+    int* d_status;
+    HIPCHK(ctx, hipMalloc((void**)&d_status, sizeof(int) * count));
+    int rc = launch_xgcd(ctx->stream, x, out, m.d_ctx /*unused*/, m.n, m.nwords, count, d_status);
+    if (rc != 0) { hipFree(d_status); return fail(ctx, SC_ERR_HIP, "xgcd launch failed"); }
+    std::vector<int> st(count);
+    HIPCHK(ctx, hipMemcpyAsync(st.data(), d_status, sizeof(int) * count, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipFree(d_status));
+    for (uint64_t i = 0; i < count; i++)
+      if (st[i] != 1) { if (bad) *bad = (int64_t)i; return fail(ctx, SC_ERR_NOT_INVERTIBLE, "element %llu is not invertible", (unsigned long long)i); }
+    return SC_OK;
+  }
+  const uint32_t K = 24;
+  const uint64_t C = (count + K - 1) / K;
+  uint32_t *d_P = nullptr, *d_tot = nullptr, *d_totinv = nullptr;
+  HIPCHK(ctx, hipMalloc((void**)&d_P, (size_t)K * C * m.S * 4));
+  HIPCHK(ctx, hipMalloc((void**)&d_tot, (size_t)C * m.nwords * 4 * 2));
+  d_totinv = d_tot + (size_t)C * m.nwords;
+  std::string k1 = "inv1:" + std::to_string(mod), k2 = "inv2:" + std::to_string(mod);
+  auto it1 = ctx->progs.find(k1);
+  if (it1 == ctx->progs.end()) {
+    Builder bd;
+    for (uint32_t i = 0; i < K; i++) {
+      bd.loadw(0, i); bd.mul_const(0);
+      if (i > 0) bd.mul_extl(1, i - 1);
+      bd.storel(1, i);
+    }
+    bd.redc(); bd.storew(2); bd.end();
+    Prog p; int rc = finalize_prog(ctx, m, bd, &p); if (rc) return rc;
+    it1 = ctx->progs.emplace(k1, p).first;
+  }
+  auto it2 = ctx->progs.find(k2);
+  if (it2 == ctx->progs.end()) {
+    Builder bd;
+    bd.loadw(3); bd.mul_const(0);                         // inv (Montgomery form) of the chunk product
+    for (uint32_t i = K - 1; i >= 1; i--) {
+      bd.stt(0);
+      bd.mul_extl(1, i - 1); bd.redc(); bd.storew(4, i);  // x_i^-1 = inv * prefix_{i-1}
+      bd.loadw(0, i); bd.mul_const(0); bd.mul_tbl(0);     // inv *= x_i
+    }
+    bd.redc(); bd.storew(4, 0); bd.end();
+    Prog p; int rc = finalize_prog(ctx, m, bd, &p); if (rc) return rc;
+    it2 = ctx->progs.emplace(k2, p).first;
+  }
+  int rc;
+  {
+    VmExt ex[3] = {mk_ext(x, m.nwords, m.nwords, count), mk_ext(d_P, m.S, 0, (uint64_t)K * C), mk_ext(d_tot, m.nwords, m.nwords)};
+    rc = run_vm(ctx, mod, it1->second, ex, 3, C);
+  }
+  int64_t bad_chunk = -1;
+  if (!rc) rc = modinv_rec(ctx, mod, d_tot, d_totinv, C, &bad_chunk, depth + 1);
+  if (!rc) {
+    VmExt ex[5] = {mk_ext(x, m.nwords, m.nwords, count), mk_ext(d_P, m.S, 0, (uint64_t)K * C), mk_ext(nullptr, 0, 0),
+                   mk_ext(d_totinv, m.nwords, m.nwords), mk_ext(out, m.nwords, m.nwords, count)};
+    rc = run_vm(ctx, mod, it2->second, ex, 5, C);
+  }
+  if (rc == SC_ERR_NOT_INVERTIBLE && bad && bad_chunk >= 0) *bad = bad_chunk;  // index of a chunk member
+  hipStreamSynchronize(ctx->stream);
+  hipFree(d_P); hipFree(d_tot);
+  return rc;
+}
+
+int sc_modinv(sc_ctx* ctx, int mod, const uint32_t* x, uint32_t* out, uint64_t count, int64_t* bad_index) {
+  if (!valid_mod(ctx, mod) || !x || !out) return fail(ctx, SC_ERR_ARG, "sc_modinv: bad argument");
+  if (count == 0) return SC_OK;
+  if (bad_index) *bad_index = -1;
+  return modinv_rec(ctx, mod, x, out, count, bad_index, 0);
+}
+
+int sc_dgk_step4(sc_ctx* ctx, int mod, int cst_g, int cst_ginv, int l, const uint32_t* beta, const uint32_t* beta_inv,
+                 const uint32_t* d, const uint32_t* d_inv, const uint64_t* alpha, const uint64_t* alpha_tilde,
+                 const uint64_t* rsmall, const uint64_t* delta_a, uint32_t* c_out, uint64_t count) {
+  if (!valid_mod(ctx, mod) || l <= 0 || l > 64 || !beta || !beta_inv || !d || !d_inv || !alpha || !alpha_tilde || !rsmall || !delta_a || !c_out)
+    return fail(ctx, SC_ERR_ARG, "sc_dgk_step4: bad argument");
+  if (cst_g < 0 || cst_ginv < 0 || cst_g >= (int)ctx->consts.size() || cst_ginv >= (int)ctx->consts.size() ||
+      ctx->consts[cst_g].mod != mod || ctx->consts[cst_ginv].mod != mod)
+    return fail(ctx, SC_ERR_ARG, "sc_dgk_step4: bad constant");
+  const Mod& m = ctx->mods[mod];
+  std::string key = "step4:" + std::to_string(mod) + ":" + std::to_string(cst_g) + ":" + std::to_string(cst_ginv) + ":" + std::to_string(l);
+  // ---- launch (a): per comparison park  one, g^s*, d', d'^-1 ... in a limb-form side buffer `park` [NP][count][S]
+  //   entries: 0 = one, 1 = d' (Montgomery), 2 = d'^-1, 3 = gs0 = g^s, 4 = gs1 = g^s * g, 5 = g^delta_a
+  const int NP = 6;
+  uint32_t* d_park;
+  HIPCHK(ctx, hipMalloc((void**)&d_park, (size_t)NP * count * m.S * 4));
+  std::string ka = key + ":a", kb = key + ":b";
+  auto ita = ctx->progs.find(ka);
+  if (ita == ctx->progs.end()) {
+    Builder bd; const int cg = bd.use_const(cst_g), cgi = bd.use_const(cst_ginv);
+    // scratch: 0 one, 1 g, 2 ginv, 3 d, 4 dinv
+    bd.loadt_const(1); bd.stt(0); bd.storel(4, 0);
+    bd.loadt_const(cg); bd.stt(1);
+    bd.loadt_const(cgi); bd.stt(2);
+    bd.loadw(0); bd.mul_const(0); bd.stt(3);
+    bd.loadw(1); bd.mul_const(0); bd.stt(4);
+    // d' = rsmall ? one : d ; d'^-1 likewise   (SC/initiator.py:289-290: [d] <- [0] = g^0 = 1)
+    bd.loadt_tblsel(2, 0, 2, 0, 3, 3, 0, 0); bd.storel(4, 1);
+    bd.loadt_tblsel(2, 0, 2, 0, 4, 4, 0, 0); bd.storel(4, 2);
+    // gs0 = g^s, s = 1 - 2 delta_a  (delta_a = 1 -> g^-1, SC/initiator.py:459-461)
+    bd.loadt_tblsel(3, 0, 3, 0, 1, 1, 2, 2); bd.storel(4, 3);
+    bd.mul_tbl(1); bd.storel(4, 4);                      // gs1 = g^s * g^1   (alpha_i = 1, :476)
+    bd.loadt_tblsel(3, 0, 3, 0, 0, 0, 1, 1); bd.storel(4, 5);   // g^delta_a (:484)
+    bd.end();
+    Prog p; int rc = finalize_prog(ctx, m, bd, &p); if (rc) { hipFree(d_park); return rc; }
+    ita = ctx->progs.emplace(ka, p).first;
+  }
+  {
+    VmExt ex[5] = {mk_ext(d, m.nwords, m.nwords), mk_ext(d_inv, m.nwords, m.nwords), mk_ext(rsmall, 2, 2), mk_ext(delta_a, 2, 2),
+                   mk_ext(d_park, m.S, 0)};
+    int rc = run_vm(ctx, mod, ita->second, ex, 5, count); if (rc) { hipFree(d_park); return rc; }
+  }
+  // ---- launch (b): the bit loop i = l-1 .. 0 (SC/initiator.py:471-482) then c_-1 (:484)
+  auto itb = ctx->progs.find(kb);
+  if (itb == ctx->progs.end()) {
+    Builder bd;
+    // ext: 0 beta, 1 beta_inv, 2 park, 3 alpha, 4 alpha_tilde, 5 out
+    // scratch: 0 one, 1 d', 2 d'inv, 3 gs0, 4 gs1, 5 beta_i, 6 beta_i^-1, 7 g*beta_inv (xor when alpha_i=1), 8 w_sum, 9 xor*dinv, 10 xor, 11 w_sum^3 / tmp, 12 g
+    for (int e = 0; e < 5; e++) { bd.loadt_extl(2, e); bd.stt(e); }
+    // g itself = gs1 * gs0^-1 is not needed: xor for alpha_i = 1 is [1] * [beta_i]^-1 = g * beta_inv; park g as entry 12 via gs: g = (delta_a ? gs1*g^2.. ) -> simpler: constant
+    bd.touch(12);
+    for (int i = l - 1; i >= 0; i--) {
+      bd.loadw(0, i); bd.mul_const(0); bd.stt(5);                         // beta_i (Montgomery)
+      bd.loadw(1, i); bd.mul_const(0); bd.stt(6);                         // beta_i^-1
+      bd.mul_tbl(12); bd.stt(7);                                          // g * beta_i^-1          (4d, alpha_i = 1, :320)
+      // xor_i = alpha_i ? entry 7 : entry 5
+      bd.loadt_tblsel(3, i, 3, i, 5, 5, 7, 7); bd.stt(10);
+      // w_i = (alpha_i != alpha_tilde_i) ? xor_i * d'^-1 : xor_i          (4e, :368-371)   flags: fa = alpha_i, fb = alpha_tilde_i
+      bd.mul_tblsel(3, i, 4, i, 0, 2, 2, 0);
+      for (int k = 0; k < i; k++) bd.sqr();                               // w_i^(2^i)              (4f, :406)
+      bd.stt(9);
+      // c_i = g^s * g^alpha_i * D[alpha_tilde_i - alpha_i] * beta_i^-1 * (w_sum)^3       (4h, :471-482)
+      //   D: (fa, fb) = (0,0) -> one ; (0,1) -> d' (alpha_tilde - alpha = +1) ; (1,0) -> d'^-1 ; (1,1) -> one
+      bd.loadt_tbl(6);
+      bd.mul_tblsel(3, i, 4, i, 0, 1, 2, 0);
+      bd.mul_tblsel(3, i, 3, i, 3, 3, 4, 4);                              // g^s or g^s g
+      if (i != l - 1) bd.mul_tbl(11);                                     // (w_sum)^3 ; first iteration: `3 * 0` is the int 0 -> [0] = 1
+      bd.redc(); bd.storew(5, i + 1);
+      // w_sum *= w_i ; keep its cube for the next bit
+      if (i == l - 1) { bd.loadt_tbl(9); } else { bd.loadt_tbl(8); bd.mul_tbl(9); }
+      bd.stt(8);
+      if (i > 0) { bd.sqr(); bd.mul_tbl(8); bd.stt(11); }
+    }
+    bd.loadt_extl(2, 5); bd.mul_tbl(8); bd.redc(); bd.storew(5, 0);       // c_-1 = g^delta_a * w_sum (:484)
+    bd.end();
+    // entry 12 (g) is written by a tiny prologue: prepend ops
+    Builder pre; const int cg = pre.use_const(cst_g);
+    pre.loadt_const(cg); pre.stt(12);
+    pre.ops.insert(pre.ops.end(), bd.ops.begin(), bd.ops.end());
+    pre.nscratch = std::max(pre.nscratch, bd.nscratch); pre.muls = bd.muls; pre.redcs = bd.redcs;
+    Prog p; int rc = finalize_prog(ctx, m, pre, &p); if (rc) { hipFree(d_park); return rc; }
+    itb = ctx->progs.emplace(kb, p).first;
+  }
+  int rc;
+  {
+    VmExt ex[6] = {mk_ext(beta, m.nwords, m.nwords), mk_ext(beta_inv, m.nwords, m.nwords), mk_ext(d_park, m.S, 0),
+                   mk_ext(alpha, 2, 2), mk_ext(alpha_tilde, 2, 2), mk_ext(c_out, m.nwords, m.nwords)};
+    rc = run_vm(ctx, mod, itb->second, ex, 6, count);
+  }
+  hipStreamSynchronize(ctx->stream);
+  hipFree(d_park);
+  return rc;
+}
+
+int sc_peak_probe(sc_ctx* ctx, double* out_mac_per_s) {
+  if (!ctx || !out_mac_per_s) return SC_ERR_ARG;
+  uint32_t* d_out;
+  const int grid = ctx->num_cu * 8;
+  HIPCHK(ctx, hipMalloc((void**)&d_out, (size_t)grid * 256 * 4));
+  hipEvent_t e0, e1; HIPCHK(ctx, hipEventCreate(&e0)); HIPCHK(ctx, hipEventCreate(&e1));
+  const int iters = 40000;
+  double best = 0;
+  for (int rep = 0; rep < 4; rep++) {
+    HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
+    hipLaunchKernelGGL(k_peak_probe, dim3(grid), dim3(256), 0, ctx->stream, d_out, 12345u, 67890u, iters);
+    HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+    HIPCHK(ctx, hipEventSynchronize(e1));
+    float ms = 0; HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
+    double rate = (double)grid * 256 * (double)iters * 8 / (ms * 1e-3);
+    if (rep > 0 && rate > best) best = rate;
+  }
+  hipEventDestroy(e0); hipEventDestroy(e1); hipFree(d_out);
+  *out_mac_per_s = best;
+  return SC_OK;
+}
+
+int sc_mac_counter(sc_ctx* ctx, int reset, double* out_macs) {
+  if (!ctx) return SC_ERR_ARG;
+  if (out_macs) *out_macs = ctx->mac_counter;
+  if (reset) ctx->mac_counter = 0;
+  return SC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+// Micro-op "VM" shared between the host program builder (sc_host.cpp part of sc_lib.hip) and the
+// device interpreter kernel (sc_kernels part).  Every batched big-integer operation of the library
+// (modular product, the three exponentiation shapes, Paillier/DGK step arithmetic, batch inversion
+// sweeps) is a short wave-uniform program over ONE accumulator ACC (limb form, in VGPRs) and a
+// per-slot scratch table in HBM; the interpreter has a single Montgomery-multiply call site so the
+// hot loop stays resident in the instruction cache.
+#pragma once
+#include <stdint.h>
+
+namespace sc {
+
+enum VmOpcode : uint32_t {
+  OP_END = 0,
+  OP_MUL = 1,        // ACC = mont(A, ACC)                     A given by akind
+  OP_LOADW = 2,      // ACC = words  ext[w1] at (off = w2), word offset w3>>16, nwords w3&0xffff (0 = ext default)
+  OP_ADDW = 3,       // ACC += words (same addressing as LOADW), lazy limb-wise add
+  OP_LOADT = 4,      // ACC = limb-form operand given by akind (table / const / fbt / ext-limbs)
+  OP_REDC = 5,       // ACC = ACC / R mod n
+  OP_STOREW = 6,     // canonical(ACC) -> words ext[w1] at off w2
+  OP_STOREFLAG = 7,  // (canonical(ACC) == const[w3]) -> u8 ext[w1] at off w2
+  OP_STT = 8,        // scratch[imm] = ACC
+  OP_ADD1 = 9,       // ACC += 1 (lazy)
+  OP_SUB1 = 10,      // ACC = (ACC - 1) mod R, exact limbs
+  OP_QUOT = 11,      // ACC = ACC / n exactly (ACC must be an exact multiple of n, value < R)
+  OP_STOREL = 12,    // limb-form store of ACC to ext[w1] at off w2 (ext stride = S)
+  OP_CANON = 13,     // ACC = canonical(ACC)
+};
+
+enum VmAKind : uint32_t {
+  AK_CONST = 0,   // w1 = LDS constant index (0 = R^2 mod n, 1 = R mod n, 2.. = extra constants)
+  AK_ACC = 1,     // the accumulator itself (squaring)
+  AK_TBL = 2,     // w1 = scratch entry
+  AK_TBLSEL = 3,  // w1 = flag descriptor (extA | bitA<<4 | extB<<12 | bitB<<16), w2 = 4 scratch entries (bytes) indexed by fa*2+fb
+  AK_TBLDIG = 4,  // w1 = ext | bitpos<<4 | width<<24 ; w2 = base scratch entry ; entry = base + digit
+  AK_FBT = 5,     // w1 = ext | bitpos<<4 | width<<24 ; w2 = window index ; row = fbt[(win << width) + digit]
+  AK_EXTW = 6,    // w1 = ext, w2 = off : plain words operand (staged through LDS)
+  AK_EXTL = 7,    // w1 = ext, w2 = off : limb-form operand in an ext array (ext stride: S, or 0 = broadcast)
+};
+
+struct VmOp {
+  uint32_t w0;  // opcode[7:0] | akind[11:8] | imm[31:16]
+  uint32_t w1, w2, w3;
+};
+
+struct VmExt {
+  const void* ptr;
+  uint32_t stride;   // u32 words between consecutive items (0 = broadcast one item)
+  uint32_t nwords;   // words per item for word-form operands
+  uint64_t limit;    // flat item indices >= limit read as the integer 1 and are not written
+};
+
+constexpr int VM_MAX_EXT = 8;
+constexpr int VM_MAX_CONST = 8;  // including R^2 and R
+
+struct VmArgs {
+  const uint32_t* modctx;   // limb form: n | R^2 mod n | R mod n   (3*S words)
+  const uint32_t* consts;   // extra limb-form constants, nconst_extra * S words
+  const VmOp* prog;
+  uint32_t* scratch;        // nslots * nscratch * S words
+  const uint32_t* fbt;      // fixed-base table rows, limb form
+  uint64_t count;           // items
+  uint32_t n0inv;
+  uint32_t nops;
+  uint32_t nconst_extra;
+  uint32_t nscratch;
+  VmExt ext[VM_MAX_EXT];
+};
+
+}  // namespace sc
