@@ -251,7 +251,7 @@ __global__ void k_plain_bob(const uint32_t* __restrict__ z, const uint32_t* __re
   const bool d = cmp < 0;
   dbit[i] = d ? 1ull : 0ull;
   const int ws = l >> 5, bs = l & 31;
-  // zeta2: first the sum z + (d ? N : 0) (fits nw words: z < (N-1)/2 when d), then an in-place
+  // zeta2: first the sum z + (d ? N : 0) (nw words + a carry word), then an in-place
   // ascending funnel shift (word o only reads words >= o).
   uint32_t* z2 = zeta2 + i * nw;
   uint64_t carry = 0;
@@ -260,8 +260,10 @@ __global__ void k_plain_bob(const uint32_t* __restrict__ z, const uint32_t* __re
     z2[k] = (uint32_t)v;
     carry = v >> 32;
   }
+  const uint32_t top = (uint32_t)carry;  // word nw of the sum (z + N may exceed nw words)
   for (int k = 0; k < nw; k++) {
-    const uint64_t lo = (k + ws < nw) ? z2[k + ws] : 0u, hi = (k + ws + 1 < nw) ? z2[k + ws + 1] : 0u;
+    const int a = k + ws, b = k + ws + 1;
+    const uint64_t lo = (a < nw) ? z2[a] : ((a == nw) ? top : 0u), hi = (b < nw) ? z2[b] : ((b == nw) ? top : 0u);
     z2[k] = (uint32_t)(((hi << 32) | lo) >> bs);
   }
   for (int k = 0; k < nw; k++) {
