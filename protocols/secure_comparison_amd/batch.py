@@ -1,0 +1,77 @@
+"""Whole-batch driver: both parties' compute for B independent comparisons, device-resident end to end.
+
+This is the unit the throughput metric is defined on: every step a1-a20 of the hot-path table,
+including all 4 + 2(l+1) randomizations of the interactive protocol (SC/initiator.py:69-175,
+SC/keyholder.py:70-133), excluding key generation, table build, host RNG and transport.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+
+from .initiator import Initiator
+from .keyholder import KeyHolder
+from .schemes import DGK, Paillier
+
+
+@dataclass
+class BatchDraws:
+    """Every random input of B comparisons as device arrays (SURVEY 8(a) note 1)."""
+
+    r: torch.Tensor                    # [B][nw]        Alice's blinding value, 0 <= r < N          (SC/initiator.py:250)
+    delta_a: torch.Tensor              # [B] u64        Alice's coin                                (:420)
+    rhos: torch.Tensor                 # [l+1][B][ew]   blinding exponents in [1, u)                (:512)
+    permutation: torch.Tensor | None   # [B][l+1] i64   shuffle (None = do_shuffle False)           (:223)
+    rho_z: torch.Tensor                # [B][nw]        Paillier randomizer base for [[z]]          (:109)
+    r_bob_dgk: torch.Tensor            # [l+1][B][er]   DGK randomizer exponents for [d], [beta_i]  (SC/keyholder.py:106-108)
+    r_alice_dgk: torch.Tensor          # [l+1][B][er]   DGK randomizer exponents for the sent [c_i] (SC/initiator.py:153-154)
+    rho_zeta_1: torch.Tensor           # [B][nw]        Paillier randomizer bases                   (SC/keyholder.py:126-128)
+    rho_zeta_2: torch.Tensor
+    rho_delta_b: torch.Tensor
+
+
+@dataclass
+class BatchTrace:
+    z_enc: torch.Tensor | None = None
+    z: torch.Tensor | None = None
+    d_enc: torch.Tensor | None = None
+    beta_enc: torch.Tensor | None = None
+    c_step4h: torch.Tensor | None = None
+    c_sent: torch.Tensor | None = None
+    delta_b: torch.Tensor | None = None
+    zeta_1_enc: torch.Tensor | None = None
+    zeta_2_enc: torch.Tensor | None = None
+    delta_b_enc: torch.Tensor | None = None
+
+
+def secure_comparison_batch(x_enc: torch.Tensor, y_enc: torch.Tensor, l: int, alice_paillier: Paillier, alice_dgk: DGK,
+                            bob_paillier: Paillier, bob_dgk: DGK, draws: BatchDraws, randomize: bool = True,
+                            trace: BatchTrace | None = None) -> torch.Tensor:
+    """[[x <= y]] for B comparisons.  x_enc, y_enc: [B][2nw] Paillier ciphertexts under Bob's key."""
+    # Alice: steps 1, 3
+    z_enc, a_plain = Initiator.step_1_batch(x_enc, y_enc, l, alice_paillier, draws.r)
+    if randomize:
+        z_enc = alice_paillier.randomize_batch(z_enc, draws.rho_z)
+    # Bob: steps 2, 4a, 4b
+    b_plain = KeyHolder.step_2_batch(z_enc, l, bob_paillier)
+    d_enc, beta_enc = KeyHolder.step_4a_4b_batch(b_plain, l, bob_dgk, bob_paillier, draws.r_bob_dgk if randomize else None)
+    # Alice: steps 4c-4i
+    c_h = Initiator.step_4c_to_4h_batch(d_enc, beta_enc, a_plain, draws.delta_a, alice_dgk)
+    c_sent = Initiator.step_4i_batch(c_h, alice_dgk, draws.rhos, draws.permutation, draws.r_alice_dgk if randomize else None)
+    # Bob: steps 4j, 5
+    delta_b = KeyHolder.step_4j_batch(c_sent, bob_dgk)
+    zeta_1_enc, zeta_2_enc, delta_b_enc = KeyHolder.step_5_batch(b_plain, delta_b, bob_paillier)
+    if randomize:
+        count = zeta_1_enc.shape[0]
+        rnd = bob_paillier.randomize_batch(torch.cat([zeta_1_enc, zeta_2_enc, delta_b_enc], dim=0),
+                                           torch.cat([draws.rho_zeta_1, draws.rho_zeta_2, draws.rho_delta_b], dim=0))
+        zeta_1_enc, zeta_2_enc, delta_b_enc = rnd[:count], rnd[count:2 * count], rnd[2 * count:]
+    # Alice: steps 6, 7
+    blta = Initiator.step_6_batch(draws.delta_a, delta_b_enc, alice_paillier)
+    result = Initiator.step_7_batch(zeta_1_enc, zeta_2_enc, a_plain, l, blta, alice_paillier)
+    if trace is not None:
+        trace.z_enc, trace.z, trace.d_enc, trace.beta_enc = z_enc, b_plain.z, d_enc, beta_enc
+        trace.c_step4h, trace.c_sent, trace.delta_b = c_h, c_sent, delta_b
+        trace.zeta_1_enc, trace.zeta_2_enc, trace.delta_b_enc = zeta_1_enc, zeta_2_enc, delta_b_enc
+    return result

@@ -1,0 +1,268 @@
+"""Alice -- the party that holds [[x]], [[y]] and learns [[x <= y]].
+
+Same constructor, properties, coroutine and static step names as the reference's Initiator
+(/root/reference/src/tno/mpc/protocols/secure_comparison/initiator.py, cited as SC/initiator.py:line), with two
+differences that make the arithmetic reproducible and batchable:
+
+* every random draw can be injected (`r=`, `delta_a=`, `rhos=`, `permutation=`); when omitted it is drawn from
+  `secrets` exactly where the reference draws it;
+* each step has a `*_batch` twin working on device arrays of B comparisons (bit-major for the per-bit vectors),
+  which is what the GPU path is built for.  The single-ciphertext steps run on the GPU too (batches of one).
+"""
+from __future__ import annotations
+
+import secrets
+from dataclasses import dataclass
+from typing import Any, Sequence, cast
+
+import torch
+
+from .communicator import Communicator
+from .schemes import DGK, DGKCiphertext, Paillier, PaillierCiphertext
+from .utils import to_bits
+
+
+@dataclass
+class AlicePlain:
+    """Plaintext-side values Alice derives from her blinding value r (one entry per comparison)."""
+
+    r: torch.Tensor            # [B][nw]   r, 0 <= r < N                       (SC/initiator.py:250)
+    m1: torch.Tensor           # [B][nw+1] 2^l + r                            (:256)
+    alpha: torch.Tensor        # [B] u64   r mod 2^l                           (:270)
+    alpha_tilde: torch.Tensor  # [B] u64   (r - N) mod 2^l                     (:373)
+    r_small: torch.Tensor      # [B] u64   [r < (N-1)//2]                      (:289, :559)
+    r_shift: torch.Tensor      # [B][nw]   r div 2^l                           (:562)
+
+
+class Initiator:
+    """Player Alice."""
+
+    def __init__(self, l_maximum_bit_length: int, communicator: Communicator | None = None, other_party: str = "",
+                 scheme_paillier: Paillier | None = None, scheme_dgk: DGK | None = None, session_id: int = 0) -> None:
+        self.l_maximum_bit_length = l_maximum_bit_length
+        self.communicator = communicator
+        self.other_party = other_party
+        self._scheme_paillier = scheme_paillier
+        self._scheme_dgk = scheme_dgk
+        self.session_id = session_id
+
+    @property
+    def scheme_paillier(self) -> Paillier:
+        if self._scheme_paillier is None:
+            raise ValueError("No Paillier scheme has been initialized or received.")
+        return self._scheme_paillier
+
+    @property
+    def scheme_dgk(self) -> DGK:
+        if self._scheme_dgk is None:
+            raise ValueError("No DGK scheme has been initialized or received.")
+        return self._scheme_dgk
+
+    # ------------------------------------------------------------------ interactive protocol (one comparison)
+    async def perform_secure_comparison(self, x: PaillierCiphertext | float, y: PaillierCiphertext | float) -> PaillierCiphertext:
+        """All of Alice's steps with the message exchange of SC/initiator.py:69-175."""
+        if self.communicator is None:
+            raise ValueError("Communicator not properly initialized.")
+        self.session_id += 1
+        sid = self.session_id
+        await self.receive_encryption_schemes(sid)
+        self._start_randomness_generation()
+        l = self.l_maximum_bit_length
+        pai, dgk = self.scheme_paillier, self.scheme_dgk
+        x_enc = x if isinstance(x, PaillierCiphertext) else pai.unsafe_encrypt(x)
+        y_enc = y if isinstance(y, PaillierCiphertext) else pai.unsafe_encrypt(y)
+
+        z_enc, r = Initiator.step_1(x_enc, y_enc, l, pai)
+        z_enc.randomize()
+        await self.communicator.send(self.other_party, z_enc, msg_id=f"step_1_session_{sid}")
+        alpha = Initiator.step_3(r, l)
+        d_enc, beta_is_enc = await self.communicator.recv(self.other_party, msg_id=f"step_4b_session_{sid}")
+        d_enc = Initiator.step_4c(d_enc, r, dgk, pai)
+        xor_is_enc = Initiator.step_4d(alpha, beta_is_enc)
+        w_is_enc, alpha_tilde = Initiator.step_4e(r, alpha, xor_is_enc, d_enc, pai)
+        w_is_enc = Initiator.step_4f(w_is_enc)
+        s, delta_a = Initiator.step_4g()
+        c_is_enc = Initiator.step_4h(s, alpha, alpha_tilde, d_enc, beta_is_enc, w_is_enc, delta_a, dgk)
+        c_is_enc = Initiator.step_4i(c_is_enc, dgk, do_shuffle=True)
+        for c in c_is_enc:
+            c.randomize()
+        await self.communicator.send(self.other_party, c_is_enc, msg_id=f"step_4i_session_{sid}")
+        zeta_1_enc, zeta_2_enc, delta_b_enc = await self.communicator.recv(self.other_party, msg_id=f"step_5_session_{sid}")
+        beta_lt_alpha_enc = Initiator.step_6(delta_a, delta_b_enc)
+        return Initiator.step_7(zeta_1_enc, zeta_2_enc, r, l, beta_lt_alpha_enc, pai)
+
+    async def receive_encryption_schemes(self, session_id: int = 1) -> None:
+        """Receive Bob's public schemes; a pre-set scheme must match (SC/initiator.py:177-203)."""
+        if self.communicator is None:
+            raise ValueError("Communicator not properly initialized.")
+        got_paillier, got_dgk = await self.communicator.recv(self.other_party, msg_id=f"schemes_session_{session_id}")
+        if self._scheme_paillier is None:
+            self._scheme_paillier = got_paillier
+        elif self._scheme_paillier != got_paillier:
+            raise ValueError("Readily available Paillier scheme and received Paillier scheme are different.")
+        if self._scheme_dgk is None:
+            self._scheme_dgk = got_dgk
+        elif self._scheme_dgk != got_dgk:
+            raise ValueError("Readily available DGK scheme and received DGK scheme are different.")
+
+    def _start_randomness_generation(self) -> None:
+        """1 Paillier + (l+1) DGK randomizers, exactly what one comparison consumes (SC/initiator.py:205-210)."""
+        self.scheme_paillier.boot_randomness_generation(1)
+        self.scheme_dgk.boot_randomness_generation(self.l_maximum_bit_length + 1)
+
+    @staticmethod
+    def shuffle(values: list[Any], permutation: Sequence[int] | None = None) -> list[Any]:
+        """Random reordering (SC/initiator.py:212-226); `permutation[k]` = source index of output k when injected."""
+        if permutation is None:
+            permutation = list(range(len(values)))
+            for k in range(len(permutation) - 1, 0, -1):  # Fisher-Yates on crypto randomness
+                j = secrets.randbelow(k + 1)
+                permutation[k], permutation[j] = permutation[j], permutation[k]
+        return [values[k] for k in permutation]
+
+    # ------------------------------------------------------------------ single-ciphertext steps
+    @staticmethod
+    def step_1(x_enc: PaillierCiphertext, y_enc: PaillierCiphertext, l: int, scheme_paillier: Paillier,
+               r: int | None = None) -> tuple[PaillierCiphertext, int]:
+        """[[z]] = [[y - x + 2^l + r]] (SC/initiator.py:228-258)."""
+        n = scheme_paillier.public_key.n
+        assert (1 << (l + 2)) < n // 2
+        if r is None:
+            r = secrets.randbelow(n)
+        blind = scheme_paillier.unsafe_encrypt((1 << l) + r, apply_encoding=False)
+        return y_enc - x_enc + blind, r
+
+    @staticmethod
+    def step_3(r: int, l: int) -> list[int]:
+        """alpha = r mod 2^l as bits (SC/initiator.py:260-270)."""
+        return to_bits(r % (1 << l), l)
+
+    @staticmethod
+    def step_4c(d_enc: DGKCiphertext, r: int, scheme_dgk: DGK, scheme_paillier: Paillier) -> DGKCiphertext:
+        """[d] <- [0] when r < (N-1)/2 (SC/initiator.py:272-291)."""
+        n = scheme_paillier.public_key.n
+        assert 0 <= r < n
+        return scheme_dgk.unsafe_encrypt(0, apply_encoding=False) if r < (n - 1) // 2 else d_enc
+
+    @staticmethod
+    def step_4d(alpha: list[int], beta_is_enc: list[DGKCiphertext]) -> list[DGKCiphertext]:
+        """[alpha_i xor beta_i] (SC/initiator.py:293-328)."""
+        return [b_enc if a_i == 0 else 1 - b_enc for a_i, b_enc in zip(alpha, beta_is_enc)]
+
+    @staticmethod
+    def step_4e(r: int, alpha: list[int], alpha_is_xor_beta_is_enc: list[DGKCiphertext], d_enc: DGKCiphertext,
+                scheme_paillier: Paillier) -> tuple[list[DGKCiphertext], list[int]]:
+        """alpha~ and the carry-corrected [w_i] (SC/initiator.py:330-384)."""
+        l = len(alpha_is_xor_beta_is_enc)
+        alpha_tilde = to_bits((r - scheme_paillier.public_key.n) % (1 << l), l)
+        w = [x if a == at else x - d_enc for a, at, x in zip(alpha, alpha_tilde, alpha_is_xor_beta_is_enc)]
+        return w, alpha_tilde
+
+    @staticmethod
+    def step_4f(w_is_enc: list[DGKCiphertext]) -> list[DGKCiphertext]:
+        """[w_i] <- [w_i]^(2^i) (SC/initiator.py:386-410)."""
+        return [w * (1 << i) for i, w in enumerate(w_is_enc)]
+
+    @staticmethod
+    def step_4g(delta_a: int | None = None) -> tuple[int, int]:
+        """delta_A random bit, s = 1 - 2 delta_A (SC/initiator.py:412-421)."""
+        if delta_a is None:
+            delta_a = secrets.randbelow(2)
+        return 1 - 2 * delta_a, delta_a
+
+    @staticmethod
+    def step_4h(s: int, alpha: list[int], alpha_tilde: list[int], d_enc: DGKCiphertext, beta_is_enc: list[DGKCiphertext],
+                w_is_enc: list[DGKCiphertext], delta_a: int, scheme_dgk: DGK) -> list[DGKCiphertext]:
+        """[c_-1], [c_0], ..., [c_{l-1}] (SC/initiator.py:423-485)."""
+        l = len(beta_is_enc)
+        d_pow = {-1: d_enc * -1, 0: d_enc * 0, 1: d_enc * 1}
+        out: list[DGKCiphertext | None] = [None] * l
+        w_sum: int | DGKCiphertext = 0
+        for i in reversed(range(l)):
+            c_i = scheme_dgk.unsafe_encrypt(s, apply_encoding=False)
+            c_i += int(alpha[i]) + d_pow[alpha_tilde[i] - alpha[i]] - beta_is_enc[i] + 3 * w_sum
+            out[i] = c_i
+            w_sum += w_is_enc[i]
+        head = cast(DGKCiphertext, delta_a + w_sum)
+        return [head] + cast(list, out)
+
+    @staticmethod
+    def step_4i(c_is_enc: list[DGKCiphertext], scheme_dgk: DGK, do_shuffle: bool = True, rhos: Sequence[int] | None = None,
+                permutation: Sequence[int] | None = None) -> list[DGKCiphertext]:
+        """Blind every c_i with a random exponent in [1, u) and shuffle (SC/initiator.py:487-516)."""
+        u = scheme_dgk.public_key.u
+        if rhos is None:
+            rhos = [secrets.randbelow(u - 1) + 1 for _ in c_is_enc]
+        masked = [c * int(rho) for c, rho in zip(c_is_enc, rhos)]
+        return Initiator.shuffle(masked, permutation) if do_shuffle else masked
+
+    @staticmethod
+    def step_6(delta_a: int, delta_b_enc: PaillierCiphertext) -> PaillierCiphertext:
+        """[[beta < alpha]] (SC/initiator.py:518-531)."""
+        return delta_b_enc if delta_a == 1 else 1 - delta_b_enc
+
+    @staticmethod
+    def step_7(zeta_1_enc: PaillierCiphertext, zeta_2_enc: PaillierCiphertext, r: int, l: int,
+               beta_lt_alpha_enc: PaillierCiphertext, scheme_paillier: Paillier) -> PaillierCiphertext:
+        """[[x <= y]] (SC/initiator.py:533-564)."""
+        zeta_enc = zeta_1_enc if r < (scheme_paillier.public_key.n - 1) // 2 else zeta_2_enc
+        return zeta_enc - (scheme_paillier.unsafe_encrypt(r >> l, apply_encoding=False) + beta_lt_alpha_enc)
+
+    # ------------------------------------------------------------------ batched steps (device arrays)
+    @staticmethod
+    def step_1_batch(x_enc: torch.Tensor, y_enc: torch.Tensor, l: int, scheme_paillier: Paillier,
+                     r: torch.Tensor) -> tuple[torch.Tensor, AlicePlain]:
+        """B times step 1 + step 3 + the plaintext side of 4c/4e/7.  x_enc, y_enc: [B][2nw]; r: [B][nw] (injected)."""
+        n = scheme_paillier.public_key.n
+        assert (1 << (l + 2)) < n // 2
+        e = scheme_paillier.engine
+        m1, alpha, alpha_tilde, r_small, r_shift = e.plain_alice(r, n, l)
+        z = scheme_paillier.add_batch(scheme_paillier.add_batch(y_enc, scheme_paillier.neg_batch(x_enc)),
+                                      scheme_paillier.encrypt_raw_batch(m1))
+        return z, AlicePlain(r, m1, alpha, alpha_tilde, r_small, r_shift)
+
+    @staticmethod
+    def step_4c_to_4h_batch(d_enc: torch.Tensor, beta_is_enc: torch.Tensor, plain: AlicePlain, delta_a: torch.Tensor,
+                            scheme_dgk: DGK) -> torch.Tensor:
+        """Steps 4c, 4d, 4e, 4f, 4h fused for B comparisons.  beta_is_enc: [l][B][nw] bit-major; d_enc: [B][nw];
+        delta_a: [B] u64 (step 4g's draw, injected).  Returns [l+1][B][nw] = c_-1, c_0, .., c_{l-1} (not blinded)."""
+        e = scheme_dgk.engine
+        l, count, nw = beta_is_enc.shape
+        inv = scheme_dgk.neg_batch(torch.cat([beta_is_enc.reshape(l * count, nw), d_enc], dim=0))
+        beta_inv, d_inv = inv[: l * count].reshape(l, count, nw), inv[l * count:]
+        pk = scheme_dgk.public_key
+        return e.dgk_step4(scheme_dgk.mod_n, pk.g, scheme_dgk.g_inv, l, beta_is_enc, beta_inv, d_enc, d_inv, plain.alpha,
+                           plain.alpha_tilde, plain.r_small, delta_a)
+
+    @staticmethod
+    def step_4i_batch(c_is_enc: torch.Tensor, scheme_dgk: DGK, rhos: torch.Tensor, permutation: torch.Tensor | None = None,
+                      randomizer_exponents: torch.Tensor | None = None) -> torch.Tensor:
+        """Blinding c_i^rho_i (and, when `randomizer_exponents` is given, the `.randomize()` of SC/initiator.py:153-154
+        fused in: * h^r_i), then the per-comparison shuffle.  c_is_enc: [l+1][B][nw]; rhos: [l+1][B][ew];
+        permutation: [B][l+1] int64 (output k of comparison b takes blinded c at index permutation[b][k])."""
+        e = scheme_dgk.engine
+        lp1, count, nw = c_is_enc.shape
+        ubits = (scheme_dgk.public_key.u - 1).bit_length()
+        flat = e.modexp_var(scheme_dgk.mod_n, c_is_enc.reshape(lp1 * count, nw), rhos.reshape(lp1 * count, -1), ubits,
+                            scheme_dgk.fb_h if randomizer_exponents is not None else None,
+                            None if randomizer_exponents is None else randomizer_exponents.reshape(lp1 * count, -1))
+        out = flat.reshape(lp1, count, nw)
+        if permutation is not None:
+            idx = permutation.t().reshape(lp1, count, 1).expand(lp1, count, nw)
+            out = torch.gather(out, 0, idx)
+        return out
+
+    @staticmethod
+    def step_6_batch(delta_a: torch.Tensor, delta_b_enc: torch.Tensor, scheme_paillier: Paillier) -> torch.Tensor:
+        """[[beta < alpha]] for B comparisons: delta_b_enc where delta_a == 1 else [[1]] * delta_b_enc^-1."""
+        e = scheme_paillier.engine
+        flipped = e.modmul_const(scheme_paillier.mod_n2, scheme_paillier.neg_batch(delta_b_enc), scheme_paillier.public_key.n + 1)
+        return torch.where((delta_a != 0).reshape(-1, 1), delta_b_enc, flipped).contiguous()
+
+    @staticmethod
+    def step_7_batch(zeta_1_enc: torch.Tensor, zeta_2_enc: torch.Tensor, plain: AlicePlain, l: int,
+                     beta_lt_alpha_enc: torch.Tensor, scheme_paillier: Paillier) -> torch.Tensor:
+        """[[x <= y]] for B comparisons."""
+        zeta = torch.where((plain.r_small != 0).reshape(-1, 1), zeta_1_enc, zeta_2_enc).contiguous()
+        t = scheme_paillier.add_batch(scheme_paillier.encrypt_raw_batch(plain.r_shift), beta_lt_alpha_enc)
+        return scheme_paillier.add_batch(zeta, scheme_paillier.neg_batch(t))

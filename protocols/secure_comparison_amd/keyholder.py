@@ -1,0 +1,173 @@
+"""Bob -- the party that holds the Paillier and DGK secret keys.
+
+Same constructor, properties, coroutine and static step names as the reference's KeyHolder
+(/root/reference/src/tno/mpc/protocols/secure_comparison/keyholder.py, cited as SC/keyholder.py:line), plus
+`*_batch` twins on device arrays.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import cast
+
+import torch
+
+from .communicator import Communicator
+from .keygen import next_prime
+from .schemes import DGK, DGKCiphertext, Paillier, PaillierCiphertext
+from .utils import to_bits
+
+
+@dataclass
+class BobPlain:
+    """Plaintext-side values Bob derives from z (one entry per comparison)."""
+
+    z: torch.Tensor        # [B][nw]
+    beta: torch.Tensor     # [B] u64  z mod 2^l                           (SC/keyholder.py:196)
+    d: torch.Tensor        # [B] u64  [z < (N-1)//2]                      (:213)
+    zeta_1: torch.Tensor   # [B][nw]  z div 2^l                           (:274)
+    zeta_2: torch.Tensor   # [B][nw]  (z + N) div 2^l if d else z div 2^l (:275-282)
+
+
+class KeyHolder:
+    """Player Bob."""
+
+    def __init__(self, l_maximum_bit_length: int, communicator: Communicator | None = None, other_party: str = "",
+                 scheme_paillier: Paillier | None = None, scheme_dgk: DGK | None = None, session_id: int = 0) -> None:
+        self.l_maximum_bit_length = l_maximum_bit_length
+        self.communicator = communicator
+        self.other_party = other_party
+        self._scheme_paillier = scheme_paillier
+        self._scheme_dgk = scheme_dgk
+        self.session_id = session_id
+
+    @property
+    def scheme_paillier(self) -> Paillier:
+        if self._scheme_paillier is None:
+            raise ValueError("No Paillier scheme has been initialized or received.")
+        return self._scheme_paillier
+
+    @property
+    def scheme_dgk(self) -> DGK:
+        if self._scheme_dgk is None:
+            raise ValueError("No DGK scheme has been initialized or received.")
+        return self._scheme_dgk
+
+    # ------------------------------------------------------------------ interactive protocol (one comparison)
+    async def perform_secure_comparison(self) -> None:
+        """All of Bob's steps with the message exchange of SC/keyholder.py:70-133."""
+        if self.communicator is None:
+            raise ValueError("Communicator not properly initialized.")
+        self.session_id += 1
+        sid = self.session_id
+        await self.make_and_send_encryption_schemes(sid)
+        self._start_randomness_generation()
+        l = self.l_maximum_bit_length
+        pai, dgk = self.scheme_paillier, self.scheme_dgk
+
+        z_enc = await self.communicator.recv(self.other_party, msg_id=f"step_1_session_{sid}")
+        z, beta = KeyHolder.step_2(z_enc, l, pai)
+        d_enc = KeyHolder.step_4a(z, dgk, pai, l)
+        beta_is_enc = KeyHolder.step_4b(beta, l, dgk)
+        d_enc.randomize()
+        for b in beta_is_enc:
+            b.randomize()
+        await self.communicator.send(self.other_party, (d_enc, beta_is_enc), msg_id=f"step_4b_session_{sid}")
+        c_is_enc = await self.communicator.recv(self.other_party, msg_id=f"step_4i_session_{sid}")
+        delta_b = KeyHolder.step_4j(c_is_enc, dgk)
+        zeta_1_enc, zeta_2_enc, delta_b_enc = KeyHolder.step_5(z, l, delta_b, pai)
+        for ct in (zeta_1_enc, zeta_2_enc, delta_b_enc):
+            ct.randomize()
+        await self.communicator.send(self.other_party, (zeta_1_enc, zeta_2_enc, delta_b_enc), msg_id=f"step_5_session_{sid}")
+
+    async def make_and_send_encryption_schemes(self, session_id: int = 1, key_length_paillier: int = 2048,
+                                               v_bits_dgk: int = 160, n_bits_dgk: int = 2048) -> None:
+        """Create missing schemes (defaults of SC/keyholder.py:138-140, u = next_prime(2^(l+2)) :164) and send the
+        public parts to Alice (:168-172)."""
+        if self.communicator is None:
+            raise ValueError("Communicator not properly initialized.")
+        if self._scheme_paillier is None:
+            self._scheme_paillier = Paillier.from_security_parameter(key_length=key_length_paillier)
+        if self._scheme_dgk is None:
+            self._scheme_dgk = DGK.from_security_parameter(v_bits=v_bits_dgk, n_bits=n_bits_dgk,
+                                                           u=next_prime(1 << (self.l_maximum_bit_length + 2)),
+                                                           full_decryption=False)
+        await self.communicator.send(self.other_party, (self.scheme_paillier, self.scheme_dgk),
+                                     msg_id=f"schemes_session_{session_id}")
+
+    def _start_randomness_generation(self) -> None:
+        """3 Paillier + (l+1) DGK randomizers (SC/keyholder.py:174-179)."""
+        self.scheme_paillier.boot_randomness_generation(3)
+        self.scheme_dgk.boot_randomness_generation(self.l_maximum_bit_length + 1)
+
+    # ------------------------------------------------------------------ single-ciphertext steps
+    @staticmethod
+    def step_2(z_enc: PaillierCiphertext, l: int, scheme_paillier: Paillier) -> tuple[int, int]:
+        """z = Dec([[z]]) without decoding, beta = z mod 2^l (SC/keyholder.py:181-196)."""
+        z = cast(int, scheme_paillier.decrypt(z_enc, apply_encoding=False))
+        return z, z % (1 << l)
+
+    @staticmethod
+    def step_4a(z: int, scheme_dgk: DGK, scheme_paillier: Paillier, l: int) -> DGKCiphertext:
+        """[d], d = (z < (N-1)/2) (SC/keyholder.py:198-216)."""
+        assert scheme_dgk.public_key.u > (1 << (l + 2))
+        return scheme_dgk.unsafe_encrypt(int(z < (scheme_paillier.public_key.n - 1) // 2), apply_encoding=False)
+
+    @staticmethod
+    def step_4b(beta: int, l: int, scheme_dgk: DGK) -> list[DGKCiphertext]:
+        """[beta_i], i = 0..l-1 (SC/keyholder.py:218-233)."""
+        return [scheme_dgk.unsafe_encrypt(b, apply_encoding=False) for b in to_bits(beta, l)]
+
+    @staticmethod
+    def step_4j(c_is_enc: list[DGKCiphertext], scheme_dgk: DGK) -> int:
+        """delta_B = 1 iff some c_i decrypts to zero (SC/keyholder.py:235-253); one batched zero test."""
+        e = scheme_dgk.engine
+        flags = scheme_dgk.is_zero_batch(e.upload([c.peek_value() for c in c_is_enc], scheme_dgk.mod_n.nwords))
+        return int(bool(flags.any().item()))
+
+    @staticmethod
+    def step_5(z: int, l: int, delta_b: int, scheme_paillier: Paillier) -> tuple[PaillierCiphertext, PaillierCiphertext, PaillierCiphertext]:
+        """[[zeta_1]], [[zeta_2]], [[delta_B]] (SC/keyholder.py:255-287)."""
+        n = scheme_paillier.public_key.n
+        enc = lambda m: scheme_paillier.unsafe_encrypt(m, apply_encoding=False)  # noqa: E731
+        zeta_2 = (z + n) >> l if z < (n - 1) // 2 else z >> l
+        return enc(z >> l), enc(zeta_2), enc(delta_b)
+
+    # ------------------------------------------------------------------ batched steps
+    @staticmethod
+    def step_2_batch(z_enc: torch.Tensor, l: int, scheme_paillier: Paillier) -> BobPlain:
+        """Decrypt B ciphertexts and derive beta, d, zeta_1, zeta_2."""
+        z = scheme_paillier.decrypt_raw_batch(z_enc)
+        beta, d, zeta_1, zeta_2 = scheme_paillier.engine.plain_bob(z, scheme_paillier.public_key.n, l)
+        return BobPlain(z, beta, d, zeta_1, zeta_2)
+
+    @staticmethod
+    def step_4a_4b_batch(plain: BobPlain, l: int, scheme_dgk: DGK, scheme_paillier: Paillier,
+                         randomizer_exponents: torch.Tensor | None = None) -> tuple[torch.Tensor, torch.Tensor]:
+        """[d] ([B][nw]) and [beta_i] ([l][B][nw], bit-major).  With `randomizer_exponents` ([l+1][B][ew], row 0 for d,
+        row 1+i for beta_i) the `.randomize()` calls of SC/keyholder.py:106-108 are fused in: g^bit * h^r."""
+        assert scheme_dgk.public_key.u > (1 << (l + 2))
+        count = plain.beta.shape[0]
+        shifts = torch.arange(l, device=plain.beta.device, dtype=torch.int64).reshape(l, 1)
+        bits = torch.cat([plain.d.reshape(1, count), (plain.beta.reshape(1, count) >> shifts) & 1], dim=0)  # [l+1][B]
+        enc = scheme_dgk.encrypt_bits_batch(bits.reshape(-1))
+        if randomizer_exponents is not None:
+            enc = scheme_dgk.randomize_batch(enc, randomizer_exponents.reshape((l + 1) * count, -1))
+        enc = enc.reshape(l + 1, count, -1)
+        return enc[0].contiguous(), enc[1:].contiguous()
+
+    @staticmethod
+    def step_4j_batch(c_is_enc: torch.Tensor, scheme_dgk: DGK) -> torch.Tensor:
+        """delta_B per comparison: OR over the bit axis of the zero tests.  c_is_enc: [l+1][B][nw] -> [B] u64."""
+        lp1, count, nw = c_is_enc.shape
+        flags = scheme_dgk.is_zero_batch(c_is_enc.reshape(lp1 * count, nw)).reshape(lp1, count)
+        return (flags != 0).any(dim=0).to(torch.int64)
+
+    @staticmethod
+    def step_5_batch(plain: BobPlain, delta_b: torch.Tensor, scheme_paillier: Paillier) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """[[zeta_1]], [[zeta_2]], [[delta_B]] for B comparisons (unrandomized)."""
+        nw = plain.zeta_1.shape[-1]
+        db_words = torch.zeros((delta_b.shape[0], nw), dtype=torch.int32, device=delta_b.device)
+        db_words[:, 0] = delta_b.to(torch.int32)
+        enc = scheme_paillier.encrypt_raw_batch(torch.cat([plain.zeta_1, plain.zeta_2, db_words], dim=0))
+        count = delta_b.shape[0]
+        return enc[:count], enc[count:2 * count], enc[2 * count:]
