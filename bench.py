@@ -1,0 +1,246 @@
+"""bench.py -- secure comparisons / s on MI355X (BASELINE.json metric), one process per GPU.
+
+A "step" is one full batch of B independent secure comparisons (both parties' compute, every randomization,
+SURVEY 8(d)) on synthetic inputs already resident in HBM.  Default workload = BASELINE.json configs[2]:
+B = 65536, l = 32, 2048-bit Paillier + 2048-bit DGK on one GPU.  With N > 1 ranks each rank runs its own shard
+of B comparisons (weak scaling, no data-path collective) and the [[x<=y]] results are all-gathered over RCCL.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--l 32] [--pbits 2048]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from protocols.secure_comparison_amd import DGK, Paillier  # noqa: E402
+from protocols.secure_comparison_amd.batch import BatchDraws, secure_comparison_batch  # noqa: E402
+from protocols.secure_comparison_amd.schemes import default_engine  # noqa: E402
+
+KEYS = os.path.join(ROOT, "tests", "golden", "keys.json")
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def literal_macs_per_comparison(l: int, pbits: int, dbits: int, rbits: int) -> float:
+    """SURVEY 8(d) literal op mix in 32x32->64 multiply-accumulates (window-5 modexp, comb-8 fixed base)."""
+    def mm(bits):  # CIOS Montgomery product on s 32-bit limbs
+        s = bits // 32
+        return 2 * s * s + s
+    def e_var(kbits, modbits):
+        return (kbits + -(-kbits // 5) + 30) * mm(modbits)
+    e_p = e_var(pbits, 2 * pbits)
+    e_h = -(-rbits // 8) * mm(dbits)
+    e_rho = e_var(l + 3, dbits) if False else (l + 3 + -(-(l + 3) // 5) + 10) * mm(dbits)
+    e_0 = e_var(160, dbits // 2)
+    m_n = mm(dbits)
+    return 5 * e_p + 2 * (l + 1) * e_h + (l + 1) * e_rho + (l + 1) * e_0 + l * (l - 1) / 2 * m_n + 9 * l * m_n + 3 * 2.5 * l * m_n
+
+
+def algorithmic_bytes_per_comparison(l: int, pbits: int, dbits: int, rbits: int) -> float:
+    """Unavoidable HBM I/O of the step inputs/outputs: both parties' per-bit DGK vectors in and out,
+    nine Paillier ciphertexts, and the randomness."""
+    ct_d, ct_p = dbits // 8, 2 * pbits // 8
+    rand = 2 * (l + 1) * (rbits // 8) + (l + 1) * 8 + 5 * (pbits // 8)
+    return 2 * (2 * (l + 1) * ct_d) + 9 * ct_p + rand
+
+
+def synth_inputs(eng, l, alice_p, bob_p, bob_d, B, rbits, seed):
+    """Seeded synthetic batch, generated on the device (SURVEY 8(d) 'Synthetic inputs')."""
+    g = torch.Generator(device=eng.device)
+    g.manual_seed(0xC0FFEE + seed)
+    nw = alice_p.mod_n.nwords
+    dev = eng.device
+
+    def rand_words(*shape, top_bits_clear=0):
+        w = torch.randint(-(2 ** 31), 2 ** 31, shape, generator=g, device=dev, dtype=torch.int64).to(torch.int32)
+        if top_bits_clear:
+            w[..., -1] &= (1 << (32 - top_bits_clear)) - 1
+        return w
+
+    def below_n(count):  # uniform below 2^(bits-1) <= N, never zero
+        w = rand_words(count, nw, top_bits_clear=1 + (32 * nw - alice_p.public_key.n.bit_length()))
+        w[:, 0] |= 1
+        return w
+
+    x = torch.randint(0, 2 ** l, (B,), generator=g, device=dev, dtype=torch.int64)
+    y = torch.randint(0, 2 ** l, (B,), generator=g, device=dev, dtype=torch.int64)
+    sel = torch.arange(B, device=dev) % 8
+    y = torch.where(sel == 0, x, y)
+    y = torch.where(sel == 1, torch.clamp(x + 1, max=2 ** l - 1), y)
+
+    def small_words(v):
+        w = torch.zeros((v.shape[0], nw), dtype=torch.int32, device=dev)
+        w[:, 0] = (v & 0xFFFFFFFF).to(torch.int32)
+        w[:, 1] = (v >> 32).to(torch.int32)
+        return w
+
+    x_enc = bob_p.randomize_batch(bob_p.encrypt_raw_batch(small_words(x)), below_n(B))
+    y_enc = bob_p.randomize_batch(bob_p.encrypt_raw_batch(small_words(y)), below_n(B))
+    u = bob_d.public_key.u
+    ew, er = (u.bit_length() + 31) // 32, (rbits + 31) // 32
+    rho_small = torch.randint(0, 2 ** 62, ((l + 1), B), generator=g, device=dev, dtype=torch.int64) % (u - 1) + 1 if u < 2 ** 62 else None
+    rhos = torch.zeros((l + 1, B, ew), dtype=torch.int32, device=dev)
+    if rho_small is not None:
+        rhos[..., 0] = (rho_small & 0xFFFFFFFF).to(torch.int32)
+        if ew > 1:
+            rhos[..., 1] = (rho_small >> 32).to(torch.int32)
+    else:  # l = 64: u has 67 bits; draw 66 random bits (always < u) and force non-zero
+        rhos = rand_words(l + 1, B, ew, top_bits_clear=32 * ew - (u.bit_length() - 1))
+        rhos[..., 0] |= 1
+    draws = BatchDraws(
+        r=below_n(B), delta_a=torch.randint(0, 2, (B,), generator=g, device=dev, dtype=torch.int64), rhos=rhos,
+        permutation=None, rho_z=below_n(B),
+        r_bob_dgk=rand_words(l + 1, B, er, top_bits_clear=32 * er - rbits),
+        r_alice_dgk=rand_words(l + 1, B, er, top_bits_clear=32 * er - rbits),
+        rho_zeta_1=below_n(B), rho_zeta_2=below_n(B), rho_delta_b=below_n(B))
+    return x, y, x_enc, y_enc, draws
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=65536, help="comparisons per GPU per step")
+    ap.add_argument("--l", type=int, default=32)
+    ap.add_argument("--pbits", type=int, default=2048)
+    ap.add_argument("--rbits", type=int, default=400)
+    ap.add_argument("--fb-window", type=int, default=8)
+    ap.add_argument("--no-crt", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: F811
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    keys = json.load(open(KEYS))
+    l, B = args.l, args.batch
+    pj = keys[f"paillier_{args.pbits}"]
+    dname = f"dgk_{args.pbits}_l{l}"
+    dj = keys[dname]
+    p, q = int(pj["p"], 16), int(pj["q"], 16)
+    eng = default_engine()
+    bob_p = Paillier(p * q, p, q, use_crt=not args.no_crt)
+    alice_p = bob_p.public_copy()
+    bob_d = DGK(int(dj["p"], 16) * int(dj["q"], 16), int(dj["g"], 16), int(dj["h"], 16), int(dj["u"], 16), dj["t"],
+                int(dj["p"], 16), int(dj["q"], 16), int(dj["v_p"], 16), int(dj["v_q"], 16), randomizer_bits=args.rbits,
+                fixed_base_window=args.fb_window)
+    alice_d = bob_d.public_copy()
+    _ = bob_d.fb_h, alice_d.fb_h  # build the fixed-base tables (untimed set-up, like key generation)
+    x, y, x_enc, y_enc, draws = synth_inputs(eng, l, alice_p, bob_p, bob_d, B, args.rbits, seed=rank)
+
+    def step():
+        return secure_comparison_batch(x_enc, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws, randomize=True)
+
+    def gather(res):
+        if world == 1:
+            return res
+        out = torch.empty((world * res.shape[0], res.shape[1]), dtype=res.dtype, device=res.device)
+        dist.all_gather_into_tensor(out, res.contiguous())
+        return out
+
+    for _ in range(args.warmup):
+        res = gather(step())
+    torch.cuda.synchronize()
+    # parity spot check outside the timed region: decrypt the results on the GPU and compare with x <= y
+    if args.warmup:
+        dec = bob_p.decrypt_raw_batch(res[rank * B:(rank + 1) * B] if world > 1 else res)
+        expect = (x <= y).to(torch.int32)
+        ok = bool(((dec[:, 0] == expect) & (dec[:, 1:] == 0).all(dim=1)).all().item())
+        if not ok:
+            raise SystemExit("bench.py: decrypted results differ from x <= y")
+    eng.mac_counter(reset=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = gather(step())
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    executed_macs = eng.mac_counter()
+    value = world * B * args.steps / elapsed
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel: Alice's Paillier randomizer rho^N mod N^2 (k_vm<8,18>, one launch)
+        reps = 3
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        z_dummy = x_enc
+        alice_p.randomize_batch(z_dummy, draws.rho_z)
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(reps):
+            alice_p.randomize_batch(z_dummy, draws.rho_z)
+        ev1.record()
+        torch.cuda.synchronize()
+        launch_s = ev0.elapsed_time(ev1) * 1e-3 / reps
+        s32 = 2 * args.pbits // 32
+        alg_macs = B * (args.pbits + -(-args.pbits // 5) + 30 + 1) * (2 * s32 * s32 + s32)
+        peak = eng.peak_probe()
+        lit = literal_macs_per_comparison(l, args.pbits, args.pbits, args.rbits)
+        abytes = algorithmic_bytes_per_comparison(l, args.pbits, args.pbits, args.rbits)
+        out = {
+            "metric": "secure comparisons/sec (l=%d, %d-bit keys)" % (l, args.pbits), "value": value, "unit": "comparisons/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (29-bit radix), u64 accumulate",
+            "data": "synthetic",
+            "config": {"workload": "batch %d comparisons per GPU, l=%d, %d-bit Paillier + %d-bit DGK (BASELINE configs[2])" % (B, l, args.pbits, args.pbits),
+                       "batch_per_gpu": B, "l": l, "paillier_bits": args.pbits, "dgk_bits": args.pbits, "dgk_randomizer_bits": args.rbits,
+                       "fixed_base_window": args.fb_window, "keyholder_crt": not args.no_crt, "parallelism": "shard%d" % world},
+            "roofline": {"bound": "valu-int (v_mad_u64_u32 issue; neither HBM nor MFMA bound, SURVEY 8(d))",
+                         "kernel": "k_vm<8,18>: Paillier randomizer rho^N mod N^2, B items in one launch",
+                         "achieved": alg_macs / launch_s / 1e12, "peak": peak / 1e12, "unit": "T MAC/s (32x32->64)",
+                         "frac": alg_macs / launch_s / peak, "traffic": None, "launch_ms": launch_s * 1e3,
+                         "algorithmic_macs_per_launch": alg_macs},
+            "roofline_whole_step": {"literal_macs_per_comparison": lit, "achieved": lit * value / world / 1e12, "peak": peak / 1e12,
+                                    "unit": "T MAC/s per GPU", "frac": lit * value / world / peak,
+                                    "executed_limb_macs_per_comparison": executed_macs / (B * args.steps),
+                                    "executed_frac": executed_macs / (elapsed * peak)},
+            "roofline_hbm": {"bound": "hbm", "achieved": abytes * value / world / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": abytes * value / world / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_comparison": abytes},
+        }
+        if not args.no_cpu_baseline:
+            cores = min(os.cpu_count() or 1, 16)
+            sample = args.cpu_sample or 2 * cores
+            py = "/opt/conda/bin/python3.9" if os.path.exists("/opt/conda/bin/python3.9") else sys.executable
+            try:
+                cp = subprocess.run([py, os.path.join(ROOT, "oracle", "cpu_baseline.py"), KEYS, f"paillier_{args.pbits}", dname,
+                                     str(sample), str(cores), str(args.rbits)], capture_output=True, text=True, timeout=600)
+                cb = json.loads(cp.stdout.strip().splitlines()[-1])
+                out["cpu_baseline"] = {"value": cb["value"], "unit": "comparisons/s", "cores": cb["cores"], "kind": "port",
+                                       "sample": "%d comparisons of the same workload (oracle.compare, %s) over %d processes; %d/%d correct"
+                                                 % (cb["count"], cb["arith"], cb["cores"], cb["correct"], cb["count"])}
+            except Exception as exc:  # pragma: no cover
+                out["cpu_baseline"] = {"value": None, "unit": "comparisons/s", "cores": cores, "kind": "port", "sample": f"failed: {exc}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
