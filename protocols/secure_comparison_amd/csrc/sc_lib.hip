@@ -458,6 +458,7 @@ int get_const_kred(sc_ctx* ctx, int mod, int* out_cid) {
 extern "C" {
 
 int sc_modmul(sc_ctx* ctx, int mod, const uint32_t* a, int a_stride, const uint32_t* b, int b_stride, uint32_t* out, uint64_t count) {
+  if (ctx && count == 0) return SC_OK;  // empty batch: nothing to do (pointers may be null)
   if (!valid_mod(ctx, mod) || !a || !b || !out) return fail(ctx, SC_ERR_ARG, "sc_modmul: bad argument");
   const Mod& m = ctx->mods[mod];
   std::string key = "modmul:" + std::to_string(mod);
@@ -475,6 +476,7 @@ int sc_modmul(sc_ctx* ctx, int mod, const uint32_t* a, int a_stride, const uint3
 }
 
 int sc_modmul_const(sc_ctx* ctx, int mod, const uint32_t* a, int cst, uint32_t* out, uint64_t count) {
+  if (ctx && count == 0) return SC_OK;  // empty batch: nothing to do (pointers may be null)
   if (!valid_mod(ctx, mod) || !a || !out || cst < 0 || cst >= (int)ctx->consts.size() || ctx->consts[cst].mod != mod)
     return fail(ctx, SC_ERR_ARG, "sc_modmul_const: bad argument");
   const Mod& m = ctx->mods[mod];
@@ -494,6 +496,7 @@ int sc_modmul_const(sc_ctx* ctx, int mod, const uint32_t* a, int cst, uint32_t* 
 
 static int modexp_shared_impl(sc_ctx* ctx, int mod, int exp, const uint32_t* x, int x_words, const uint32_t* mul_into,
                               uint32_t* out, uint8_t* flags, uint64_t count) {
+  if (ctx && count == 0) return SC_OK;  // empty batch: nothing to do (pointers may be null)
   if (!valid_mod(ctx, mod) || exp < 0 || exp >= (int)ctx->exps.size() || !x || (!out && !flags))
     return fail(ctx, SC_ERR_ARG, "sc_modexp_shared: bad argument");
   const Mod& m = ctx->mods[mod];
@@ -578,6 +581,7 @@ int sc_fbt_create(sc_ctx* ctx, int mod, const uint32_t* base_hptr, int exp_bits,
 }
 
 int sc_fixedbase_pow(sc_ctx* ctx, int fbt, const uint32_t* e, int ewords, const uint32_t* mul_into, uint32_t* out, uint64_t count) {
+  if (ctx && count == 0) return SC_OK;  // empty batch: nothing to do (pointers may be null)
   if (!ctx || fbt < 0 || fbt >= (int)ctx->fbts.size() || !e || !out || ewords <= 0) return fail(ctx, SC_ERR_ARG, "sc_fixedbase_pow: bad argument");
   const Fbt& f = ctx->fbts[fbt];
   const Mod& m = ctx->mods[f.mod];
@@ -599,6 +603,7 @@ int sc_fixedbase_pow(sc_ctx* ctx, int fbt, const uint32_t* e, int ewords, const 
 
 int sc_modexp_var(sc_ctx* ctx, int mod, const uint32_t* x, const uint32_t* e, int ewords, int ebits, int fbt,
                   const uint32_t* e2, int e2words, uint32_t* out, uint64_t count) {
+  if (ctx && count == 0) return SC_OK;  // empty batch: nothing to do (pointers may be null)
   if (!valid_mod(ctx, mod) || !x || !e || !out || ewords <= 0 || ebits <= 0 || ebits > 32 * ewords)
     return fail(ctx, SC_ERR_ARG, "sc_modexp_var: bad argument");
   const Mod& m = ctx->mods[mod];
@@ -629,6 +634,7 @@ int sc_modexp_var(sc_ctx* ctx, int mod, const uint32_t* x, const uint32_t* e, in
 }
 
 int sc_paillier_encrypt_raw(sc_ctx* ctx, int mod_n2, int cst_n, const uint32_t* mwords, int m_words, uint32_t* out, uint64_t count) {
+  if (ctx && count == 0) return SC_OK;  // empty batch: nothing to do (pointers may be null)
   if (!valid_mod(ctx, mod_n2) || cst_n < 0 || cst_n >= (int)ctx->consts.size() || ctx->consts[cst_n].mod != mod_n2 || !mwords || !out || m_words <= 0)
     return fail(ctx, SC_ERR_ARG, "sc_paillier_encrypt_raw: bad argument");
   const Mod& m = ctx->mods[mod_n2];
@@ -647,6 +653,7 @@ int sc_paillier_encrypt_raw(sc_ctx* ctx, int mod_n2, int cst_n, const uint32_t* 
 }
 
 int sc_paillier_l_mul(sc_ctx* ctx, int mod, int cst_k, const uint32_t* x, int x_words, uint32_t* out, uint64_t count) {
+  if (ctx && count == 0) return SC_OK;  // empty batch: nothing to do (pointers may be null)
   if (!valid_mod(ctx, mod) || cst_k < 0 || cst_k >= (int)ctx->consts.size() || ctx->consts[cst_k].mod != mod || !x || !out || x_words <= 0)
     return fail(ctx, SC_ERR_ARG, "sc_paillier_l_mul: bad argument");
   const Mod& m = ctx->mods[mod];
@@ -669,6 +676,7 @@ int sc_paillier_l_mul(sc_ctx* ctx, int mod, int cst_k, const uint32_t* x, int x_
 
 int sc_plain_alice(sc_ctx* ctx, const uint32_t* r, const uint32_t* n_hptr, int nw, int l, uint64_t count, uint32_t* m1,
                    uint64_t* alpha, uint64_t* alpha_tilde, uint64_t* rsmall, uint32_t* rshift) {
+  if (ctx && count == 0) return SC_OK;  // empty batch: nothing to do (pointers may be null)
   if (!ctx || !r || !n_hptr || nw <= 0 || l <= 0 || l > 64 || !m1 || !alpha || !alpha_tilde || !rsmall || !rshift)
     return fail(ctx, SC_ERR_ARG, "sc_plain_alice: bad argument");
   if (count == 0) return SC_OK;
@@ -687,6 +695,7 @@ int sc_plain_alice(sc_ctx* ctx, const uint32_t* r, const uint32_t* n_hptr, int n
 
 int sc_plain_bob(sc_ctx* ctx, const uint32_t* z, const uint32_t* n_hptr, int nw, int l, uint64_t count, uint64_t* beta,
                  uint64_t* dbit, uint32_t* zeta1, uint32_t* zeta2) {
+  if (ctx && count == 0) return SC_OK;  // empty batch: nothing to do (pointers may be null)
   if (!ctx || !z || !n_hptr || nw <= 0 || l <= 0 || l > 64 || !beta || !dbit || !zeta1 || !zeta2)
     return fail(ctx, SC_ERR_ARG, "sc_plain_bob: bad argument");
   if (count == 0) return SC_OK;
@@ -773,6 +782,7 @@ static int modinv_rec(sc_ctx* ctx, int mod, const uint32_t* x, uint32_t* out, ui
 }
 
 int sc_modinv(sc_ctx* ctx, int mod, const uint32_t* x, uint32_t* out, uint64_t count, int64_t* bad_index) {
+  if (ctx && count == 0) return SC_OK;  // empty batch: nothing to do (pointers may be null)
   if (!valid_mod(ctx, mod) || !x || !out) return fail(ctx, SC_ERR_ARG, "sc_modinv: bad argument");
   if (count == 0) return SC_OK;
   if (bad_index) *bad_index = -1;
@@ -782,6 +792,7 @@ int sc_modinv(sc_ctx* ctx, int mod, const uint32_t* x, uint32_t* out, uint64_t c
 int sc_dgk_step4(sc_ctx* ctx, int mod, int cst_g, int cst_ginv, int l, const uint32_t* beta, const uint32_t* beta_inv,
                  const uint32_t* d, const uint32_t* d_inv, const uint64_t* alpha, const uint64_t* alpha_tilde,
                  const uint64_t* rsmall, const uint64_t* delta_a, uint32_t* c_out, uint64_t count) {
+  if (ctx && count == 0) return SC_OK;  // empty batch: nothing to do (pointers may be null)
   if (!valid_mod(ctx, mod) || l <= 0 || l > 64 || !beta || !beta_inv || !d || !d_inv || !alpha || !alpha_tilde || !rsmall || !delta_a || !c_out)
     return fail(ctx, SC_ERR_ARG, "sc_dgk_step4: bad argument");
   if (cst_g < 0 || cst_ginv < 0 || cst_g >= (int)ctx->consts.size() || cst_ginv >= (int)ctx->consts.size() ||

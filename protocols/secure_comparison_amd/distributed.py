@@ -1,0 +1,36 @@
+"""Multi-GPU sharding of a batch of comparisons: comparisons are independent, so every rank runs all
+steps on its own contiguous block with no traffic during compute; ONE all-gather (RCCL over xGMI with the "nccl"
+backend, gloo in the CPU tests) reassembles the [[x <= y]] batch."""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous block [lo, hi) of rank `rank`; blocks differ by at most one item."""
+    base, extra = divmod(total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def all_gather_results(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
+    """Concatenate the ranks' result blocks ([count_r][words]) in rank order into [total][words]."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return local
+    sizes = [shard_bounds(total, r, world) for r in range(world)]
+    width = local.shape[-1]
+    if all(hi - lo == sizes[0][1] - sizes[0][0] for lo, hi in sizes):
+        out = torch.empty((total, width), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
+    parts = [torch.empty((hi - lo, width), dtype=local.dtype, device=local.device) for lo, hi in sizes]
+    pad = max(hi - lo for lo, hi in sizes)
+    padded = [torch.empty((pad, width), dtype=local.dtype, device=local.device) for _ in sizes]
+    mine = torch.zeros((pad, width), dtype=local.dtype, device=local.device)
+    mine[: local.shape[0]] = local
+    dist.all_gather(padded, mine, group=group)
+    for p, full in zip(parts, padded):
+        p.copy_(full[: p.shape[0]])
+    return torch.cat(parts, dim=0)

@@ -1,0 +1,43 @@
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def keys():
+    return json.load(open(os.path.join(GOLDEN, "keys.json")))
+
+
+def oracle_paillier(keys, bits):
+    from oracle import sc_oracle as o
+
+    k = keys[f"paillier_{bits}"]
+    p, q = int(k["p"], 16), int(k["q"], 16)
+    return o.PaillierKey(p * q, p, q)
+
+
+def oracle_dgk(keys, name):
+    from oracle import sc_oracle as o
+
+    k = keys[name]
+    p, q = int(k["p"], 16), int(k["q"], 16)
+    return o.DGKKey(p * q, int(k["g"], 16), int(k["h"], 16), int(k["u"], 16), k["t"], p, q, int(k["v_p"], 16), int(k["v_q"], 16))
+
+
+@pytest.fixture(scope="session")
+def engine():
+    """The HIP engine (GPU tests only).  No fallback: a missing library or GPU is a hard failure."""
+    from protocols.secure_comparison_amd.schemes import default_engine
+
+    return default_engine()

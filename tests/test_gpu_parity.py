@@ -1,0 +1,347 @@
+"""GPU parity tests proper: every call goes through the C ABI (libsc_amd.so) on a real MI355X and is compared bit
+for bit with the CPU oracle / the committed golden fixtures.  Bar: bit-exact (integer work)."""
+import asyncio
+import json
+import os
+import random
+import warnings
+
+import pytest
+import torch
+
+from conftest import GOLDEN, oracle_dgk, oracle_paillier
+from oracle import sc_oracle as o
+
+pytestmark = pytest.mark.gpu
+H = lambda s: int(s, 16)  # noqa: E731
+
+
+# ------------------------------------------------------------------------------------------ primitives
+def test_primitive_kats_all_sizes(engine):
+    """Known-answer tests at 128 / 1024 / 2048 / 3072 / 4096 / 6144 bits incl. operands 0, 1, n-1 (every kernel configuration)."""
+    for k in json.load(open(os.path.join(GOLDEN, "kat_primitives.json"))):
+        n = H(k["n"])
+        mod = engine.modulus(n)
+        a, b = engine.upload([H(x) for x in k["a"]], mod.nwords), engine.upload([H(x) for x in k["b"]], mod.nwords)
+        assert engine.download(engine.modmul(mod, a, b)) == [H(x) for x in k["mul"]], k["bits"]
+        assert engine.download(engine.modexp_shared(mod, a, H(k["e"]))) == [H(x) for x in k["pow"]], k["bits"]
+        inv = engine.modinv(mod, engine.upload([H(x) for x in k["inv_in"]], mod.nwords))
+        assert engine.download(inv) == [H(x) for x in k["inv"]], k["bits"]
+        es = [H(x) for x in k["small_e"]]
+        base = engine.upload([H(k["a"][5])] * len(es), mod.nwords)
+        got = engine.download(engine.modexp_var(mod, base, engine.upload(es, 3), 67))
+        assert got == [H(x) for x in k["pow_small"]], k["bits"]
+
+
+@pytest.mark.parametrize("count", [0, 1, 15, 17, 63, 65, 333])
+def test_ragged_and_empty_batches(engine, count):
+    rng = random.Random(count)
+    n = rng.getrandbits(2048) | (1 << 2047) | 1
+    mod = engine.modulus(n)
+    a = [rng.randrange(n) for _ in range(count)]
+    b = [rng.randrange(n) for _ in range(count)]
+    ta, tb = engine.upload(a, mod.nwords).reshape(count, mod.nwords), engine.upload(b, mod.nwords).reshape(count, mod.nwords)
+    assert engine.download(engine.modmul(mod, ta, tb)) == [x * y % n for x, y in zip(a, b)]
+    assert engine.download(engine.modexp_shared(mod, ta, 65537)) == [pow(x, 65537, n) for x in a]
+    if count:
+        inv_in = [x for x in a if _invertible(x, n)]
+        got = engine.download(engine.modinv(mod, engine.upload(inv_in, mod.nwords)))
+        assert got == [pow(x, -1, n) for x in inv_in]
+
+
+def _invertible(x, n):
+    try:
+        pow(x, -1, n)
+        return True
+    except ValueError:
+        return False
+
+
+def test_fixed_base_windows_and_fused_forms(engine):
+    rng = random.Random(3)
+    n = rng.getrandbits(2048) | (1 << 2047) | 1
+    mod = engine.modulus(n)
+    h = rng.randrange(2, n)
+    B = 70
+    c = [rng.randrange(n) for _ in range(B)]
+    r = [rng.getrandbits(400) for _ in range(B)]
+    r[0], r[1], r[2] = 0, 1, (1 << 400) - 1
+    rho = [1 + rng.randrange((1 << 34) - 1) for _ in range(B)]
+    tc, tr, trho = engine.upload(c, mod.nwords), engine.upload(r, 13), engine.upload(rho, 2)
+    for window in (1, 5, 8, 11):
+        fb = engine.fixed_base(mod, h, 400, window)
+        assert engine.download(engine.fixedbase_pow(fb, tr)) == [pow(h, x, n) for x in r]
+        assert engine.download(engine.fixedbase_pow(fb, tr, mul_into=tc)) == [pow(h, x, n) * y % n for x, y in zip(r, c)]
+        got = engine.download(engine.modexp_var(mod, tc, trho, 34, fb, tr))
+        assert got == [pow(y, e, n) * pow(h, x, n) % n for y, e, x in zip(c, rho, r)]
+
+
+def test_wide_operand_reduction_and_is_one(engine, keys):
+    d = oracle_dgk(keys, "dgk_2048_l32")
+    mp = engine.modulus(d.p)
+    rng = random.Random(9)
+    ms = [0 if i % 3 == 0 else rng.randrange(1, d.u) for i in range(50)]
+    cts = [d.randomize(d.enc_raw(m), rng.getrandbits(400)) for m in ms]
+    t = engine.upload(cts, (d.n.bit_length() + 31) // 32)
+    assert engine.modexp_shared_isone(mp, t, d.v_p).tolist() == [int(m == 0) for m in ms]
+    assert engine.download(engine.modexp_shared(mp, t, 1)) == [c % d.p for c in cts]
+
+
+def test_errors(engine):
+    from protocols.secure_comparison_amd.engine import NotInvertibleError
+
+    n = 3 * 5 * 7 * (random.Random(1).getrandbits(1000) | 1)
+    mod = engine.modulus(n)
+    with pytest.raises(NotInvertibleError):
+        engine.modinv(mod, engine.upload([2, 21, 4], mod.nwords))
+    many = [2] * 500 + [35] + [4] * 500
+    with pytest.raises(NotInvertibleError):
+        engine.modinv(mod, engine.upload(many, mod.nwords))
+    with pytest.raises(ValueError):
+        engine.modulus(1 << 64)            # even modulus
+    with pytest.raises(Exception):
+        engine.modulus((1 << 9000) + 1)    # larger than any compiled configuration
+
+
+# ------------------------------------------------------------------------------------------ scheme level
+@pytest.mark.parametrize("bits", [1024, 2048, 3072])
+def test_paillier_pieces(engine, keys, bits):
+    from protocols.secure_comparison_amd import Paillier
+
+    sk = oracle_paillier(keys, bits)
+    rng = random.Random(bits)
+    B = 40
+    ms = [0, 1, sk.n - 1] + [rng.randrange(sk.n) for _ in range(B - 3)]
+    rhos = [1 + rng.randrange(sk.n - 1) for _ in range(B)]
+    for use_crt in (False, True):
+        p = Paillier(sk.n, sk.p, sk.q, engine=engine, use_crt=use_crt)
+        nw = p.mod_n.nwords
+        enc = p.encrypt_raw_batch(engine.upload(ms, nw))
+        assert engine.download(enc) == [sk.enc_raw(m) for m in ms]
+        rnd = p.randomize_batch(enc, engine.upload(rhos, nw))
+        assert engine.download(rnd) == [sk.randomize(sk.enc_raw(m), r) for m, r in zip(ms, rhos)]
+        assert engine.download(p.decrypt_raw_batch(rnd)) == ms
+    wide = [m + (1 << 64) for m in ms]     # 2^l + r may exceed N (SC/initiator.py:256)
+    assert engine.download(p.encrypt_raw_batch(engine.upload(wide, nw + 1))) == [sk.enc_raw(m) for m in wide]
+
+
+@pytest.mark.parametrize("l", [16, 32, 64])
+def test_plaintext_side_kernels(engine, keys, l):
+    sk = oracle_paillier(keys, 2048)
+    n = sk.n
+    rng = random.Random(l)
+    rs = [0, 1, n - 1, (n - 1) // 2, (n - 1) // 2 - 1, (n - 1) // 2 + 1, (1 << l) - 1, 1 << l] + [rng.randrange(n) for _ in range(92)]
+    t = engine.upload(rs, 64)
+    M = (1 << 64) - 1
+    m1, al, at, rsm, rsh = engine.plain_alice(t, n, l)
+    assert engine.download(m1) == [(1 << l) + r for r in rs]
+    assert [v & M for v in al.tolist()] == [r % (1 << l) for r in rs]
+    assert [v & M for v in at.tolist()] == [(r - n) % (1 << l) for r in rs]
+    assert rsm.tolist() == [int(r < (n - 1) // 2) for r in rs]
+    assert engine.download(rsh) == [r >> l for r in rs]
+    be, db, z1, z2 = engine.plain_bob(t, n, l)
+    assert [v & M for v in be.tolist()] == [r % (1 << l) for r in rs]
+    assert db.tolist() == [int(r < (n - 1) // 2) for r in rs]
+    assert engine.download(z1) == [r >> l for r in rs]
+    assert engine.download(z2) == [((r + n) >> l) if r < (n - 1) // 2 else (r >> l) for r in rs]
+
+
+# ------------------------------------------------------------------------------------------ whole comparisons
+def _schemes(engine, sk, dgk, rbits, use_crt=True):
+    from protocols.secure_comparison_amd import DGK, Paillier
+
+    bob_p = Paillier(sk.n, sk.p, sk.q, engine=engine, use_crt=use_crt)
+    bob_d = DGK(dgk.n, dgk.g, dgk.h, dgk.u, dgk.t, dgk.p, dgk.q, dgk.v_p, dgk.v_q, engine=engine, randomizer_bits=rbits)
+    return bob_p.public_copy(), bob_d.public_copy(), bob_p, bob_d
+
+
+def _draw_tensors(engine, drs, l, nw, ew, er, device):
+    from protocols.secure_comparison_amd.batch import BatchDraws
+
+    B = len(drs)
+    bm = lambda rows, w: torch.stack([engine.upload([rows[b][i] for b in range(B)], w) for i in range(l + 1)])  # noqa: E731
+    has_perm = drs[0].perm is not None
+    rc = [list(d.r_c) for d in drs]
+    if has_perm:
+        rc = [[None] * (l + 1) for _ in range(B)]
+        for b, d in enumerate(drs):
+            for k, src in enumerate(d.perm):
+                rc[b][src] = d.r_c[k]
+    return BatchDraws(r=engine.upload([d.r for d in drs], nw), delta_a=engine.upload_u64([d.delta_a for d in drs]),
+                      rhos=bm([d.rhos for d in drs], ew),
+                      permutation=torch.tensor([d.perm for d in drs], dtype=torch.int64, device=device) if has_perm else None,
+                      rho_z=engine.upload([d.rho_z for d in drs], nw), r_bob_dgk=bm([[d.r_d] + d.r_beta for d in drs], er),
+                      r_alice_dgk=bm(rc, er), rho_zeta_1=engine.upload([d.rho_zeta1 for d in drs], nw),
+                      rho_zeta_2=engine.upload([d.rho_zeta2 for d in drs], nw), rho_delta_b=engine.upload([d.rho_delta_b for d in drs], nw))
+
+
+@pytest.mark.parametrize("set_index", [0, 1, 2])
+def test_golden_comparisons_through_hip(engine, keys, set_index):
+    """The committed golden comparisons (inputs, every random draw, wire values, result) reproduced by the HIP path."""
+    from protocols.secure_comparison_amd.batch import BatchTrace, secure_comparison_batch
+    from test_oracle_golden import load_draws
+
+    s = json.load(open(os.path.join(GOLDEN, "comparisons.json")))[set_index]
+    sk, dgk = oracle_paillier(keys, s["paillier_bits"]), oracle_dgk(keys, s["dgk"])
+    alice_p, alice_d, bob_p, bob_d = _schemes(engine, sk, dgk, s["rbits"])
+    items, l = s["items"], s["l"]
+    drs = [load_draws(it["draws"]) for it in items]
+    nw = bob_p.mod_n.nwords
+    draws = _draw_tensors(engine, drs, l, nw, (dgk.u.bit_length() + 31) // 32, (s["rbits"] + 31) // 32, engine.device)
+    tr = BatchTrace()
+    res = secure_comparison_batch(engine.upload([H(it["x_enc"]) for it in items], 2 * nw), engine.upload([H(it["y_enc"]) for it in items], 2 * nw),
+                                  l, alice_p, alice_d, bob_p, bob_d, draws, True, tr)
+    assert engine.download(res) == [H(it["result"]) for it in items]
+    assert engine.download(tr.z_enc) == [H(it["z_enc"]) for it in items]
+    assert engine.download(tr.z) == [H(it["z"]) for it in items]
+    assert tr.delta_b.tolist() == [it["delta_b"] for it in items]
+    for b, it in enumerate(items):
+        assert engine.download(tr.c_sent[:, b]) == [H(x) for x in it["c_sent"]]
+    static = secure_comparison_batch(engine.upload([H(it["x_enc"]) for it in items], 2 * nw), engine.upload([H(it["y_enc"]) for it in items], 2 * nw),
+                                     l, alice_p, alice_d, bob_p, bob_d, draws, False)
+    assert engine.download(static) == [H(it["result_static"]) for it in items]
+
+
+@pytest.mark.parametrize("pbits, dname, B, rbits, use_crt", [
+    (1024, "dgk_1024_l16", 40, 400, True), (1024, "dgk_1024_l16", 20, 400, False),
+    (2048, "dgk_2048_l32", 20, 400, True), (2048, "dgk_2048_l64", 6, 400, True), (3072, "dgk_3072_l64", 3, 400, True)])
+def test_random_batches_vs_oracle(engine, keys, pbits, dname, B, rbits, use_crt):
+    """Seeded random comparisons incl. equal / adjacent pairs; l = 64 exercises 67-bit blinding exponents and 3072-bit keys
+    (N^2 = 6144 bits) the largest kernel configurations (BASELINE configs[4] shape)."""
+    from protocols.secure_comparison_amd.batch import secure_comparison_batch
+
+    sk, dgk = oracle_paillier(keys, pbits), oracle_dgk(keys, dname)
+    l = keys[dname]["l"]
+    alice_p, alice_d, bob_p, bob_d = _schemes(engine, sk, dgk, rbits, use_crt)
+    rng = random.Random(pbits * 1000 + l)
+    xs = [rng.randrange(1 << l) for _ in range(B)]
+    ys = [xs[i] if i % 4 == 0 else (max(xs[i] - 1, 0) if i % 4 == 1 else rng.randrange(1 << l)) for i in range(B)]
+    drs = [o.draw(rng, l, sk, dgk, rbits) for _ in range(B)]
+    x_enc = [sk.randomize(sk.enc_raw(x), 1 + rng.randrange(sk.n - 1)) for x in xs]
+    y_enc = [sk.randomize(sk.enc_raw(y), 1 + rng.randrange(sk.n - 1)) for y in ys]
+    expect = [o.compare(a, b, l, sk, dgk, d, True) for a, b, d in zip(x_enc, y_enc, drs)]
+    nw = bob_p.mod_n.nwords
+    draws = _draw_tensors(engine, drs, l, nw, (dgk.u.bit_length() + 31) // 32, (rbits + 31) // 32, engine.device)
+    got = engine.download(secure_comparison_batch(engine.upload(x_enc, 2 * nw), engine.upload(y_enc, 2 * nw), l, alice_p, alice_d,
+                                                  bob_p, bob_d, draws))
+    assert got == expect
+    assert [sk.dec_raw(c) for c in got] == [int(x <= y) for x, y in zip(xs, ys)]
+
+
+def test_config2_full_size_property(engine, keys):
+    """BASELINE configs[1]: batch 4096, l = 16, 2048-bit keys.  Size-independent properties: Dec(result) == [x <= y] for every
+    comparison (decrypted on the GPU), and a sampled subset bit-exact against the oracle."""
+    import bench
+
+    sk, dgk = oracle_paillier(keys, 2048), oracle_dgk(keys, "dgk_2048_l16")
+    alice_p, alice_d, bob_p, bob_d = _schemes(engine, sk, dgk, 400)
+    from protocols.secure_comparison_amd.batch import secure_comparison_batch
+
+    B, l = 4096, 16
+    x, y, x_enc, y_enc, draws = bench.synth_inputs(engine, l, alice_p, bob_p, bob_d, B, 400, seed=0)
+    res = secure_comparison_batch(x_enc, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws)
+    dec = bob_p.decrypt_raw_batch(res)
+    assert bool(((dec[:, 0] == (x <= y).to(torch.int32)) & (dec[:, 1:] == 0).all(dim=1)).all().item())
+    idx = [0, 1, 2, 7, 8, 9, 1234, 4095]
+    ints = lambda t: engine.download(t[idx])  # noqa: E731
+    perb = lambda t: [engine.download(t[:, i]) for i in idx]  # noqa: E731
+    M = (1 << 64) - 1
+    rows = zip(ints(x_enc), ints(y_enc), ints(draws.r), [int(v) & M for v in draws.delta_a[idx].tolist()], perb(draws.rhos),
+               ints(draws.rho_z), perb(draws.r_bob_dgk), perb(draws.r_alice_dgk), ints(draws.rho_zeta_1), ints(draws.rho_zeta_2),
+               ints(draws.rho_delta_b))
+    expect = []
+    for xe, ye, r, da, rhos, rho_z, rb, rc, z1, z2, zb in rows:
+        dr = o.Draws(r=r, delta_a=da, rhos=rhos, perm=None, rho_z=rho_z, r_d=rb[0], r_beta=rb[1:], r_c=rc, rho_zeta1=z1,
+                     rho_zeta2=z2, rho_delta_b=zb)
+        expect.append(o.compare(xe, ye, l, sk, dgk, dr, True))
+    assert ints(res) == expect
+
+
+# ------------------------------------------------------------------------------------------ reference-style object API on the GPU
+def test_object_api_reference_identities(engine, keys):
+    """A condensed replay of the reference's unit tests (test_secure_comparison.py:196-635) on the product's own classes."""
+    from protocols.secure_comparison_amd import DGK, Initiator, KeyHolder, Paillier, PaillierCiphertext, to_bits
+
+    sk, od = oracle_paillier(keys, 1024), oracle_dgk(keys, "dgk_tiny_l16")
+    paillier = Paillier(sk.n, sk.p, sk.q, engine=engine)
+    dgk_full = DGK(od.n, od.g, od.h, od.u, od.t, od.p, od.q, od.v_p, od.v_q, full_decryption=True, engine=engine, randomizer_bits=50)
+    l, n, u = 16, sk.n, od.u
+    # test_modulo_n_squared (:166-182)
+    y_enc = PaillierCiphertext(paillier.public_key.n_squared - 2, paillier)
+    y = paillier.decrypt(y_enc, apply_encoding=False)
+    z_enc = y_enc - paillier.unsafe_encrypt(0, apply_encoding=False) + paillier.unsafe_encrypt((1 << l) + n * n, apply_encoding=False)
+    assert (y + (1 << l) + n * n) % (n * n) == paillier.decrypt(z_enc, apply_encoding=False)
+    for x, y in ((-400, -383), (230, 269), (8668, 9015)):
+        x_enc, y_enc = paillier.unsafe_encrypt(x), paillier.unsafe_encrypt(y)
+        z_enc, r = Initiator.step_1(x_enc, y_enc, l, paillier)
+        assert paillier.decrypt(paillier.unsafe_encrypt((y - x + (1 << l) + r) % (n * n), apply_encoding=False)) == paillier.decrypt(z_enc)
+        z, beta = KeyHolder.step_2(z_enc, l, paillier)
+        alpha = Initiator.step_3(r, l)
+        d_enc = Initiator.step_4c(KeyHolder.step_4a(z, dgk_full, paillier, l), r, dgk_full, paillier)
+        beta_is_enc = KeyHolder.step_4b(beta, l, dgk_full)
+        assert [dgk_full.decrypt(b) for b in beta_is_enc] == to_bits(beta, l)
+        xor = Initiator.step_4d(alpha, beta_is_enc)
+        w_is_enc, alpha_tilde = Initiator.step_4e(r, alpha, xor, d_enc, paillier)
+        d = dgk_full.decrypt(d_enc)
+        beta_bits = to_bits(beta, l)
+        w_plain = [((alpha[i] ^ beta_bits[i]) - (0 if alpha[i] == alpha_tilde[i] else d)) % u for i in range(l)]
+        assert [dgk_full.decrypt(w, apply_encoding=False) for w in w_is_enc] == w_plain
+        w_is_enc = Initiator.step_4f(w_is_enc)
+        w_plain = [w * 2 ** i % u for i, w in enumerate(w_plain)]
+        assert [dgk_full.decrypt(w, apply_encoding=False) for w in w_is_enc] == w_plain
+        s, delta_a = Initiator.step_4g()
+        c_is_enc = Initiator.step_4h(s, alpha, alpha_tilde, d_enc, beta_is_enc, w_is_enc, delta_a, dgk_full)
+        for i in range(l):
+            t = s + alpha[i] + (alpha_tilde[i] - alpha[i]) * d - beta_bits[i] + 3 * sum(w_plain[i + 1:])
+            assert t % u == dgk_full.decrypt(c_is_enc[i + 1], apply_encoding=False)
+        c_is_enc = Initiator.step_4i(c_is_enc, dgk_full)
+        delta_b = KeyHolder.step_4j(c_is_enc, dgk_full)
+        assert delta_b == int(any(dgk_full.is_zero(c) for c in c_is_enc))
+        zeta_1, zeta_2, delta_b_enc = KeyHolder.step_5(z, l, delta_b, paillier)
+        res = Initiator.step_7(zeta_1, zeta_2, r, l, Initiator.step_6(delta_a, delta_b_enc), paillier)
+        assert paillier.decrypt(res) == int(x <= y)
+    for z, delta_b in ((n, 0), (100, 1)):      # test_step_5 (:548-566)
+        z1, z2, db = KeyHolder.step_5(z, l, delta_b, paillier)
+        assert paillier.decrypt(z1, apply_encoding=False) == (z >> l) % n and paillier.decrypt(db) == delta_b
+        assert paillier.decrypt(z2, apply_encoding=False) == (((z + n) >> l) if z < (n - 1) // 2 else (z >> l)) % n
+
+
+def test_interactive_protocol_on_gpu_strict(engine, keys):
+    """Both players over an in-memory transport with warnings-as-errors (the reference's strict fixtures,
+    test/conftest.py:26-36; flows of test_secure_comparison.py:641-835)."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(__file__))
+    from _comm import DictionaryCommunicator
+    from protocols.secure_comparison_amd import DGK, Initiator, KeyHolder, Paillier
+
+    sk, od = oracle_paillier(keys, 1024), oracle_dgk(keys, "dgk_1024_l16")
+    bob_p = Paillier(sk.n, sk.p, sk.q, engine=engine)
+    bob_d = DGK(od.n, od.g, od.h, od.u, od.t, od.p, od.q, od.v_p, od.v_q, engine=engine)
+    box = {}
+    alice = Initiator(16, DictionaryCommunicator(box), "bob")
+    bob = KeyHolder(16, DictionaryCommunicator(box), "alice", bob_p, bob_d)
+
+    async def go(x, y):
+        res, _ = await asyncio.gather(alice.perform_secure_comparison(x, y), bob.perform_secure_comparison())
+        return res
+
+    with warnings.catch_warnings():
+        warnings.filterwarnings("error", ".*ciphertext", UserWarning)
+        warnings.filterwarnings("error", ".*randomness", UserWarning)
+        for x, y in ((23, 42), (42, 23), (9, 9)):
+            assert bob_p.decrypt(asyncio.run(go(x, y))) == int(x <= y)
+    assert alice.scheme_paillier == bob_p and alice.scheme_dgk == bob_d
+    bob_p.shut_down(), bob_d.shut_down()
+
+
+def test_key_generation_and_fresh_keys(engine):
+    """from_security_parameter (SC/keyholder.py:156-166) with small sizes: fresh keys work end to end on the GPU."""
+    from protocols.secure_comparison_amd import DGK, Initiator, KeyHolder, Paillier
+    from protocols.secure_comparison_amd.keygen import next_prime
+
+    pai = Paillier.from_security_parameter(key_length=512, engine=engine)
+    dgk = DGK.from_security_parameter(v_bits=40, n_bits=512, u=next_prime(1 << 10), full_decryption=True, engine=engine)
+    assert dgk.decrypt(dgk.encrypt(5) + dgk.encrypt(-2)) == 3 and pai.decrypt(pai.encrypt(-7) * 3) == -21
+    z_enc, r = Initiator.step_1(pai.unsafe_encrypt(3), pai.unsafe_encrypt(4), 8, pai)
+    assert KeyHolder.step_2(z_enc, 8, pai)[0] == (4 - 3 + 256 + r) % pai.public_key.n

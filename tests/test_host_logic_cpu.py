@@ -1,0 +1,195 @@
+"""Host-side logic of the product (step choreography, operator algebra, bit-major batch layout, protocol driver,
+error behaviour) exercised on the CPU with the test-only OracleEngine standing in for the HIP engine.
+The arithmetic itself is checked on the GPU (tests/test_gpu_*.py)."""
+import asyncio
+import random
+import warnings
+
+import pytest
+import torch
+
+from _comm import DictionaryCommunicator
+from _oracle_engine import OracleEngine
+from conftest import oracle_dgk, oracle_paillier
+from oracle import sc_oracle as o
+from protocols.secure_comparison_amd import DGK, Initiator, KeyHolder, Paillier, PaillierCiphertext
+from protocols.secure_comparison_amd.batch import BatchDraws, BatchTrace, secure_comparison_batch
+
+L = 16
+
+
+@pytest.fixture(scope="module")
+def world(keys):
+    osk, od = oracle_paillier(keys, 1024), oracle_dgk(keys, "dgk_tiny_l16")
+    eng = OracleEngine()
+    bob_p = Paillier(osk.n, osk.p, osk.q, engine=eng)
+    bob_d = DGK(od.n, od.g, od.h, od.u, od.t, od.p, od.q, od.v_p, od.v_q, full_decryption=True, engine=eng, randomizer_bits=50)
+    return osk, od, eng, bob_p, bob_d
+
+
+def test_operator_algebra_matches_oracle(world):
+    osk, od, eng, pai, dgk = world
+    a, b = pai.unsafe_encrypt(5), pai.unsafe_encrypt(-3)
+    assert (a + b).value == osk.add(osk.enc_raw(5), osk.enc_raw(osk.encode(-3)))
+    assert (a - b).value == osk.add(osk.enc_raw(5), osk.neg(osk.enc_raw(osk.encode(-3))))
+    assert (1 - a).value == osk.add(osk.neg(osk.enc_raw(5)), osk.enc_raw(1))
+    assert (a * 7).value == osk.mul(osk.enc_raw(5), 7) and (a * -1).value == osk.neg(osk.enc_raw(5))
+    assert pai.decrypt(a - b) == 8 and pai.decrypt(b) == -3 and pai.decrypt(b, apply_encoding=False) == osk.n - 3
+    c = dgk.unsafe_encrypt(-1, apply_encoding=False)
+    assert c.value == od.enc_raw(-1) == o.mod_inv(od.g, od.n)           # g^-1, not g^(u-1)  (SURVEY 8(a) note 2)
+    assert (c * 0).value == 1 and (3 * c).value == od.mul(c.value, 3) and (2 + c).value == od.add(c.value, od.enc_raw(2))
+    assert dgk.decrypt(dgk.unsafe_encrypt(5) + dgk.unsafe_encrypt(9)) == 14 and dgk.is_zero(dgk.unsafe_encrypt(0))
+
+
+def test_single_steps_match_oracle(world):
+    osk, od, eng, pai, dgk = world
+    rng = random.Random(4)
+    for x, y in ((23, 42), (42, 23), (-400, -383), (7, 7)):
+        dr = o.draw(rng, L, osk, od, 50, shuffle=True)
+        x_enc, y_enc = pai.unsafe_encrypt(x), pai.unsafe_encrypt(y)
+        z_enc, r = Initiator.step_1(x_enc, y_enc, L, pai, r=dr.r)
+        z, beta = KeyHolder.step_2(z_enc, L, pai)
+        alpha = Initiator.step_3(r, L)
+        d_enc = KeyHolder.step_4a(z, dgk, pai, L)
+        beta_enc = KeyHolder.step_4b(beta, L, dgk)
+        d_enc = Initiator.step_4c(d_enc, r, dgk, pai)
+        xor = Initiator.step_4d(alpha, beta_enc)
+        w, alpha_tilde = Initiator.step_4e(r, alpha, xor, d_enc, pai)
+        w = Initiator.step_4f(w)
+        s, delta_a = Initiator.step_4g(dr.delta_a)
+        c = Initiator.step_4h(s, alpha, alpha_tilde, d_enc, beta_enc, w, delta_a, dgk)
+        c = Initiator.step_4i(c, dgk, do_shuffle=True, rhos=dr.rhos, permutation=dr.perm)
+        delta_b = KeyHolder.step_4j(c, dgk)
+        z1, z2, db = KeyHolder.step_5(z, L, delta_b, pai)
+        res = Initiator.step_7(z1, z2, r, L, Initiator.step_6(delta_a, db), pai)
+        assert res.value == o.compare(x_enc.value, y_enc.value, L, osk, od, dr, randomize=False)
+        assert pai.decrypt(res) == int(x <= y)
+
+
+def test_step_guards(world):
+    osk, od, eng, pai, dgk = world
+    with pytest.raises(AssertionError):
+        Initiator.step_1(pai.unsafe_encrypt(1), pai.unsafe_encrypt(2), osk.n.bit_length() - 2, pai)
+    for r in (-10, osk.n + 10):
+        with pytest.raises(AssertionError):
+            Initiator.step_4c(dgk.unsafe_encrypt(0), r, dgk, pai)
+    with pytest.raises(AssertionError):
+        KeyHolder.step_4a(5, dgk, pai, 40)  # u must exceed 2^(l+2)
+    with pytest.raises(ValueError):
+        Initiator(L).scheme_paillier
+    with pytest.raises(ValueError):
+        KeyHolder(L).scheme_dgk
+    with pytest.raises(ValueError):
+        asyncio.run(Initiator(L).perform_secure_comparison(1, 2))
+    with pytest.raises(ValueError):
+        asyncio.run(KeyHolder(L).perform_secure_comparison())
+
+
+def _interactive(world, x, y, strict=True, sessions=1):
+    osk, od, eng, bob_p, bob_d = world
+    box = {}
+    alice = Initiator(L, communicator=DictionaryCommunicator(box), other_party="bob")
+    bob = KeyHolder(L, communicator=DictionaryCommunicator(box), other_party="alice", scheme_paillier=bob_p, scheme_dgk=bob_d)
+
+    async def go():
+        out = []
+        for _ in range(sessions):
+            res, _ = await asyncio.gather(alice.perform_secure_comparison(x, y), bob.perform_secure_comparison())
+            out.append(res)
+        return out
+
+    with warnings.catch_warnings():
+        if strict:  # the reference's strict fixtures: randomness / ciphertext warnings are errors (test/conftest.py:26-36)
+            warnings.filterwarnings("error", ".*ciphertext", UserWarning)
+            warnings.filterwarnings("error", ".*randomness", UserWarning)
+        return asyncio.run(go()), alice, bob
+
+
+@pytest.mark.parametrize("x, y", [(23, 42), (42, 23), (-1, 0), (5, 5)])
+def test_interactive_protocol_exact_randomness_budget(world, x, y):
+    res, alice, bob = _interactive(world, x, y, strict=True, sessions=2)
+    assert [world[3].decrypt(r) for r in res] == [int(x <= y)] * 2
+    assert alice.session_id == 2 and bob.session_id == 2
+    # the boot counts 1/(l+1) and 3/(l+1) are exactly what one comparison consumes: pools are empty afterwards
+    assert not alice.scheme_paillier._pool and not alice.scheme_dgk._pool and not world[3]._pool and not world[4]._pool
+
+
+def test_parallel_sessions_are_namespaced(world):
+    osk, od, eng, bob_p, bob_d = world
+    box = {}
+    a1 = Initiator(L, DictionaryCommunicator(box), "bob", session_id=0)
+    a2 = Initiator(L, DictionaryCommunicator(box), "bob", session_id=10)
+    b1 = KeyHolder(L, DictionaryCommunicator(box), "alice", bob_p, bob_d, session_id=0)
+    b2 = KeyHolder(L, DictionaryCommunicator(box), "alice", bob_p, bob_d, session_id=10)
+
+    async def go():
+        return await asyncio.gather(a1.perform_secure_comparison(3, 9), a2.perform_secure_comparison(9, 3),
+                                    b1.perform_secure_comparison(), b2.perform_secure_comparison())
+
+    r = asyncio.run(go())
+    assert bob_p.decrypt(r[0]) == 1 and bob_p.decrypt(r[1]) == 0
+
+
+def test_mismatching_scheme_raises_valueerror(world, keys):
+    osk, od, eng, bob_p, bob_d = world
+    other = oracle_paillier(keys, 2048)
+    box = {}
+    alice = Initiator(L, DictionaryCommunicator(box), "bob", scheme_paillier=Paillier(other.n, engine=eng))
+    bob = KeyHolder(L, DictionaryCommunicator(box), "alice", bob_p, bob_d)
+
+    async def go():
+        await asyncio.gather(alice.perform_secure_comparison(1, 2), bob.make_and_send_encryption_schemes(1))
+
+    with pytest.raises(ValueError, match=".*Paillier"):
+        asyncio.run(go())
+
+
+def test_randomize_warnings(world):
+    osk, od, eng, pai, dgk = world
+    pai.shut_down()
+    ct = pai.unsafe_encrypt(3)
+    with pytest.warns(UserWarning, match=".*randomness"):
+        ct.randomize()                       # pool empty -> generated on the fly
+    with pytest.warns(UserWarning, match=".*ciphertext"):
+        pai.boot_randomness_generation(1)
+        ct.randomize()                       # already fresh
+    assert pai.decrypt(ct) == 3
+
+
+def make_draws(eng, drs, l, nw, ew, er):
+    B = len(drs)
+    bm = lambda rows, w: torch.stack([eng.upload([rows[b][i] for b in range(B)], w) for i in range(l + 1)])  # noqa: E731
+    inv_rc = [[None] * (l + 1) for _ in range(B)]
+    for b, d in enumerate(drs):   # the oracle randomizes after the shuffle: map r_c back to pre-shuffle positions
+        for k, src in enumerate(d.perm):
+            inv_rc[b][src] = d.r_c[k]
+    return BatchDraws(r=eng.upload([d.r for d in drs], nw), delta_a=eng.upload_u64([d.delta_a for d in drs]),
+                      rhos=bm([d.rhos for d in drs], ew), permutation=torch.tensor([d.perm for d in drs], dtype=torch.int64),
+                      rho_z=eng.upload([d.rho_z for d in drs], nw), r_bob_dgk=bm([[d.r_d] + d.r_beta for d in drs], er),
+                      r_alice_dgk=bm(inv_rc, er), rho_zeta_1=eng.upload([d.rho_zeta1 for d in drs], nw),
+                      rho_zeta_2=eng.upload([d.rho_zeta2 for d in drs], nw), rho_delta_b=eng.upload([d.rho_delta_b for d in drs], nw))
+
+
+@pytest.mark.parametrize("use_crt", [False, True])
+def test_batch_driver_layout_and_shuffle(world, use_crt):
+    """Bit-major layouts, the permutation gather, fused randomizer ordering and the CRT recombination, vs the oracle."""
+    osk, od, eng, _, bob_d = world
+    bob_p = Paillier(osk.n, osk.p, osk.q, engine=eng, use_crt=use_crt)
+    rng = random.Random(77)
+    B = 7  # ragged on purpose
+    xs = [rng.randrange(1 << L) for _ in range(B)]
+    ys = [xs[i] if i % 3 == 0 else rng.randrange(1 << L) for i in range(B)]
+    drs = [o.draw(rng, L, osk, od, 50) for _ in range(B)]
+    x_enc = [osk.randomize(osk.enc_raw(x), 1 + rng.randrange(osk.n - 1)) for x in xs]
+    y_enc = [osk.randomize(osk.enc_raw(y), 1 + rng.randrange(osk.n - 1)) for y in ys]
+    traces = [dict() for _ in range(B)]
+    expect = [o.compare(a, b, L, osk, od, d, True, t) for a, b, d, t in zip(x_enc, y_enc, drs, traces)]
+    nw = bob_p.mod_n.nwords
+    draws = make_draws(eng, drs, L, nw, (od.u.bit_length() + 31) // 32, 2)
+    tr = BatchTrace()
+    got = secure_comparison_batch(eng.upload(x_enc, 2 * nw), eng.upload(y_enc, 2 * nw), L, bob_p.public_copy(), bob_d.public_copy(),
+                                  bob_p, bob_d, draws, True, tr)
+    assert eng.download(got) == expect
+    assert [eng.download(tr.c_sent[:, b])for b in range(B)] == [t["c_enc"] for t in traces]
+    assert tr.delta_b.tolist() == [t["delta_b"] for t in traces]
+    assert [osk.dec_raw(v) for v in eng.download(got)] == [int(x <= y) for x, y in zip(xs, ys)]
