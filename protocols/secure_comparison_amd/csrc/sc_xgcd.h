@@ -153,7 +153,8 @@ inline int launch_xgcd(hipStream_t stream, const uint32_t* x, uint32_t* out, con
   return e == hipSuccess ? 0 : -1;
 }
 
-// v_mad_u64_u32 issue-rate probe (8 independent accumulators per lane)
+// v_mad_u64_u32 issue-rate probe: 8 independent accumulator chains per lane, nothing else in the loop
+// (same kernel as tools/microbench/probe.hip::k_mad64, which measured 3.1e13 lane-MAC/s at 8 waves/SIMD).
 __global__ void k_peak_probe(uint32_t* out, uint32_t a0, uint32_t b0, int iters) {
   uint32_t a = a0 + threadIdx.x, b = b0 ^ threadIdx.x;
   uint64_t acc[8];
@@ -161,8 +162,8 @@ __global__ void k_peak_probe(uint32_t* out, uint32_t a0, uint32_t b0, int iters)
   for (int i = 0; i < 8; i++) acc[i] = i + threadIdx.x;
   for (int it = 0; it < iters; it++) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) acc[i] = (uint64_t)a * b + acc[i];
-    a += 2;  // keep the multiplications from being hoisted
+    for (int i = 0; i < 8; i++)
+      asm volatile("v_mad_u64_u32 %0, s[20:21], %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b) : "s20", "s21");
   }
   uint64_t s = 0;
 #pragma unroll
