@@ -113,10 +113,11 @@ def main() -> None:
     ap.add_argument("--l", type=int, default=32)
     ap.add_argument("--pbits", type=int, default=2048)
     ap.add_argument("--rbits", type=int, default=400)
-    ap.add_argument("--fb-window", type=int, default=8)
+    ap.add_argument("--fb-window", type=int, default=13)
     ap.add_argument("--no-crt", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0)
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (exercises the RCCL path)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -126,9 +127,11 @@ def main() -> None:
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist  # noqa: F811
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     keys = json.load(open(KEYS))
     l, B = args.l, args.batch
@@ -150,7 +153,7 @@ def main() -> None:
         return secure_comparison_batch(x_enc, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws, randomize=True)
 
     def gather(res):
-        if world == 1:
+        if dist is None:
             return res
         out = torch.empty((world * res.shape[0], res.shape[1]), dtype=res.dtype, device=res.device)
         dist.all_gather_into_tensor(out, res.contiguous())
@@ -167,17 +170,17 @@ def main() -> None:
         if not ok:
             raise SystemExit("bench.py: decrypted results differ from x <= y")
     eng.mac_counter(reset=True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = gather(step())
     torch.cuda.synchronize()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -250,7 +253,7 @@ def main() -> None:
             except Exception as exc:  # pragma: no cover
                 out["cpu_baseline"] = {"value": None, "unit": "comparisons/s", "cores": cores, "kind": "port", "sample": f"failed: {exc}"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -35,7 +35,7 @@ __device__ __forceinline__ uint32_t bcast0(uint32_t v) {  // value of the group'
     return __builtin_amdgcn_update_dpp(0u, v, 0x150, 0xf, 0xf, false);  // row_newbcast:0
   } else {
     static_assert(G == 8, "unsupported group size");
-    uint32_t lo = __builtin_amdgcn_update_dpp(0u, v, 0x150, 0xf, 0x3, false);  // lanes 0-7  <- lane 0
+    uint32_t lo = __builtin_amdgcn_update_dpp(v, v, 0x150, 0xf, 0x3, false);   // lanes 0-7  <- lane 0 (others keep v for now)
     return __builtin_amdgcn_update_dpp(lo, v, 0x158, 0xf, 0xc, false);         // lanes 8-15 <- lane 8
   }
 }
@@ -75,6 +75,9 @@ struct Grp {
   __device__ __forceinline__ uint32_t from_above(uint32_t v) const {
     if constexpr (G == 1) return 0u; else return row_from_above(v) & notTop;
   }
+  __device__ __forceinline__ uint32_t from_above_raw(uint32_t v) const {
+    if constexpr (G == 1) return 0u; else return row_from_above(v);
+  }
   __device__ __forceinline__ uint32_t from_below(uint32_t v) const {
     if constexpr (G == 1) return 0u; else return row_from_below(v) & notBot;
   }
@@ -113,7 +116,10 @@ struct Grp {
         for (int c = 0; c < L; c++) T[(l + c) % L] += (uint64_t)q * n[c];
         const uint64_t t0 = T[l];                 // column 0: its low 29 bits are 0 in lane 0
         T[(l + 1) % L] += t0 >> W;                // carry into column 1
-        T[l] = (uint64_t)from_above((uint32_t)t0 & LMASK);  // becomes the new top column
+        // The low limb moves to the lane below and becomes its new top column.  No group-boundary mask is needed:
+        // the bottom lane of the group above contributes exactly 0 (its column 0 was just made divisible by 2^29),
+        // and the DPP row end reads 0 (bound_ctrl).
+        T[l] = (uint64_t)from_above_raw((uint32_t)t0 & LMASK);
       }
     }
     // one local carry pass + hand the lane carry to the next lane (result "almost normalised")

@@ -109,6 +109,8 @@ struct sc_ctx {
   std::vector<void*> owned;
   double mac_counter = 0;
   std::map<int, int> occ_cache;  // config index -> blocks per CU
+  std::map<int, std::pair<void*, size_t>> tmp;          // grow-only temporaries, reused across calls (same stream => ordered)
+  std::map<std::vector<uint32_t>, uint32_t*> nwords_cache;  // device copy of {n, (n-1)/2} for the plain-word kernels
 };
 
 namespace {
@@ -138,6 +140,36 @@ int ensure_scratch(sc_ctx* ctx, size_t bytes) {
   size_t want = bytes + bytes / 4;
   HIPCHK(ctx, hipMalloc((void**)&ctx->scratch, want));
   ctx->scratch_bytes = want;
+  return SC_OK;
+}
+
+// Temporary device buffer `slot`, at least `bytes` large.  Buffers are reused by later calls: every kernel of a context
+// runs on one stream, so a later call cannot overtake an earlier one that still reads the buffer.
+int tmp_buf(sc_ctx* ctx, int slot, size_t bytes, void** out) {
+  auto& e = ctx->tmp[slot];
+  if (e.second < bytes) {
+    if (e.first) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(e.first)); e.first = nullptr; e.second = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    HIPCHK(ctx, hipMalloc(&e.first, want));
+    e.second = want;
+  }
+  *out = e.first;
+  return SC_OK;
+}
+enum TmpSlot { TMP_PARK = 1, TMP_XGCD_STATUS = 2, TMP_INV_BASE = 16 /* + 2*depth, + 2*depth+1 */ };
+
+// device copy of n | (n-1)/2 as canonical words (plain-word kernels)
+int device_n_half(sc_ctx* ctx, const uint32_t* n_hptr, int nw, uint32_t** out) {
+  std::vector<uint32_t> n(n_hptr, n_hptr + nw);
+  auto it = ctx->nwords_cache.find(n);
+  if (it != ctx->nwords_cache.end()) { *out = it->second; return SC_OK; }
+  std::vector<uint32_t> both(2 * nw);
+  for (int k = 0; k < nw; k++) { both[k] = n[k]; both[nw + k] = (n[k] >> 1) | ((k + 1 < nw) ? (n[k + 1] << 31) : 0u); }
+  uint32_t* d = nullptr;
+  int rc = upload(ctx, both.data(), both.size() * 4, (void**)&d);
+  if (rc) return rc;
+  ctx->nwords_cache[n] = d;
+  *out = d;
   return SC_OK;
 }
 
@@ -353,6 +385,7 @@ void sc_ctx_destroy(sc_ctx* ctx) {
   hipDeviceSynchronize();
   for (void* p : ctx->owned) hipFree(p);
   if (ctx->scratch) hipFree(ctx->scratch);
+  for (auto& kv : ctx->tmp) if (kv.second.first) hipFree(kv.second.first);
   delete ctx;
 }
 
@@ -680,16 +713,10 @@ int sc_plain_alice(sc_ctx* ctx, const uint32_t* r, const uint32_t* n_hptr, int n
   if (!ctx || !r || !n_hptr || nw <= 0 || l <= 0 || l > 64 || !m1 || !alpha || !alpha_tilde || !rsmall || !rshift)
     return fail(ctx, SC_ERR_ARG, "sc_plain_alice: bad argument");
   if (count == 0) return SC_OK;
-  Big n(n_hptr, n_hptr + nw), half(nw);
-  for (int k = 0; k < nw; k++) half[k] = (n[k] >> 1) | ((k + 1 < nw) ? (n[k + 1] << 31) : 0u);  // (N-1)/2 for odd N
-  uint32_t *d_n, *d_h;
-  HIPCHK(ctx, hipMalloc((void**)&d_n, nw * 8)); d_h = d_n + nw;
-  HIPCHK(ctx, hipMemcpyAsync(d_n, n.data(), nw * 4, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(d_h, half.data(), nw * 4, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_plain_alice, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, r, d_n, d_h, nw, l, count, m1, alpha, alpha_tilde, rsmall, rshift);
+  uint32_t* d_n = nullptr;
+  { int rc = device_n_half(ctx, n_hptr, nw, &d_n); if (rc) return rc; }
+  hipLaunchKernelGGL(k_plain_alice, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, r, d_n, d_n + nw, nw, l, count, m1, alpha, alpha_tilde, rsmall, rshift);
   HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  HIPCHK(ctx, hipFree(d_n));
   return SC_OK;
 }
 
@@ -699,16 +726,10 @@ int sc_plain_bob(sc_ctx* ctx, const uint32_t* z, const uint32_t* n_hptr, int nw,
   if (!ctx || !z || !n_hptr || nw <= 0 || l <= 0 || l > 64 || !beta || !dbit || !zeta1 || !zeta2)
     return fail(ctx, SC_ERR_ARG, "sc_plain_bob: bad argument");
   if (count == 0) return SC_OK;
-  Big n(n_hptr, n_hptr + nw), half(nw);
-  for (int k = 0; k < nw; k++) half[k] = (n[k] >> 1) | ((k + 1 < nw) ? (n[k + 1] << 31) : 0u);
-  uint32_t *d_n, *d_h;
-  HIPCHK(ctx, hipMalloc((void**)&d_n, nw * 8)); d_h = d_n + nw;
-  HIPCHK(ctx, hipMemcpyAsync(d_n, n.data(), nw * 4, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(d_h, half.data(), nw * 4, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_plain_bob, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, z, d_n, d_h, nw, l, count, beta, dbit, zeta1, zeta2);
+  uint32_t* d_n = nullptr;
+  { int rc = device_n_half(ctx, n_hptr, nw, &d_n); if (rc) return rc; }
+  hipLaunchKernelGGL(k_plain_bob, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, z, d_n, d_n + nw, nw, l, count, beta, dbit, zeta1, zeta2);
   HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  HIPCHK(ctx, hipFree(d_n));
   return SC_OK;
 }
 
@@ -720,13 +741,14 @@ static int modinv_rec(sc_ctx* ctx, int mod, const uint32_t* x, uint32_t* out, ui
   const uint64_t TOP = 48;
   if (count <= TOP) {
     int* d_status;
-    HIPCHK(ctx, hipMalloc((void**)&d_status, sizeof(int) * count));
-    int rc = launch_xgcd(ctx->stream, x, out, m.d_ctx /*unused*/, m.n, m.nwords, count, d_status);
-    if (rc != 0) { hipFree(d_status); return fail(ctx, SC_ERR_HIP, "xgcd launch failed"); }
+    { int rc0 = tmp_buf(ctx, TMP_XGCD_STATUS, sizeof(int) * count, (void**)&d_status); if (rc0) return rc0; }
+    uint32_t* d_nw = nullptr;
+    { int rc0 = device_n_half(ctx, m.n.data(), m.nwords, &d_nw); if (rc0) return rc0; }
+    int rc = launch_xgcd(ctx->stream, x, out, d_nw, m.nwords, count, d_status);
+    if (rc != 0) return fail(ctx, SC_ERR_HIP, "xgcd launch failed");
     std::vector<int> st(count);
     HIPCHK(ctx, hipMemcpyAsync(st.data(), d_status, sizeof(int) * count, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    HIPCHK(ctx, hipFree(d_status));
     for (uint64_t i = 0; i < count; i++)
       if (st[i] != 1) { if (bad) *bad = (int64_t)i; return fail(ctx, SC_ERR_NOT_INVERTIBLE, "element %llu is not invertible", (unsigned long long)i); }
     return SC_OK;
@@ -734,8 +756,8 @@ static int modinv_rec(sc_ctx* ctx, int mod, const uint32_t* x, uint32_t* out, ui
   const uint32_t K = 24;
   const uint64_t C = (count + K - 1) / K;
   uint32_t *d_P = nullptr, *d_tot = nullptr, *d_totinv = nullptr;
-  HIPCHK(ctx, hipMalloc((void**)&d_P, (size_t)K * C * m.S * 4));
-  HIPCHK(ctx, hipMalloc((void**)&d_tot, (size_t)C * m.nwords * 4 * 2));
+  { int rc0 = tmp_buf(ctx, TMP_INV_BASE + 2 * depth, (size_t)K * C * m.S * 4, (void**)&d_P); if (rc0) return rc0; }
+  { int rc0 = tmp_buf(ctx, TMP_INV_BASE + 2 * depth + 1, (size_t)C * m.nwords * 4 * 2, (void**)&d_tot); if (rc0) return rc0; }
   d_totinv = d_tot + (size_t)C * m.nwords;
   std::string k1 = "inv1:" + std::to_string(mod), k2 = "inv2:" + std::to_string(mod);
   auto it1 = ctx->progs.find(k1);
@@ -776,8 +798,6 @@ static int modinv_rec(sc_ctx* ctx, int mod, const uint32_t* x, uint32_t* out, ui
     rc = run_vm(ctx, mod, it2->second, ex, 5, C);
   }
   if (rc == SC_ERR_NOT_INVERTIBLE && bad && bad_chunk >= 0) *bad = bad_chunk;  // index of a chunk member
-  hipStreamSynchronize(ctx->stream);
-  hipFree(d_P); hipFree(d_tot);
   return rc;
 }
 
@@ -804,7 +824,7 @@ int sc_dgk_step4(sc_ctx* ctx, int mod, int cst_g, int cst_ginv, int l, const uin
   //   entries: 0 = one, 1 = d' (Montgomery), 2 = d'^-1, 3 = gs0 = g^s, 4 = gs1 = g^s * g, 5 = g^delta_a
   const int NP = 6;
   uint32_t* d_park;
-  HIPCHK(ctx, hipMalloc((void**)&d_park, (size_t)NP * count * m.S * 4));
+  { int rc0 = tmp_buf(ctx, TMP_PARK, (size_t)NP * count * m.S * 4, (void**)&d_park); if (rc0) return rc0; }
   std::string ka = key + ":a", kb = key + ":b";
   auto ita = ctx->progs.find(ka);
   if (ita == ctx->progs.end()) {
@@ -823,13 +843,13 @@ int sc_dgk_step4(sc_ctx* ctx, int mod, int cst_g, int cst_ginv, int l, const uin
     bd.mul_tbl(1); bd.storel(4, 4);                      // gs1 = g^s * g^1   (alpha_i = 1, :476)
     bd.loadt_tblsel(3, 0, 3, 0, 0, 0, 1, 1); bd.storel(4, 5);   // g^delta_a (:484)
     bd.end();
-    Prog p; int rc = finalize_prog(ctx, m, bd, &p); if (rc) { hipFree(d_park); return rc; }
+    Prog p; int rc = finalize_prog(ctx, m, bd, &p); if (rc) return rc;
     ita = ctx->progs.emplace(ka, p).first;
   }
   {
     VmExt ex[5] = {mk_ext(d, m.nwords, m.nwords), mk_ext(d_inv, m.nwords, m.nwords), mk_ext(rsmall, 2, 2), mk_ext(delta_a, 2, 2),
                    mk_ext(d_park, m.S, 0)};
-    int rc = run_vm(ctx, mod, ita->second, ex, 5, count); if (rc) { hipFree(d_park); return rc; }
+    int rc = run_vm(ctx, mod, ita->second, ex, 5, count); if (rc) return rc;
   }
   // ---- launch (b): the bit loop i = l-1 .. 0 (SC/initiator.py:471-482) then c_-1 (:484)
   auto itb = ctx->progs.find(kb);
@@ -869,7 +889,7 @@ int sc_dgk_step4(sc_ctx* ctx, int mod, int cst_g, int cst_ginv, int l, const uin
     pre.loadt_const(cg); pre.stt(12);
     pre.ops.insert(pre.ops.end(), bd.ops.begin(), bd.ops.end());
     pre.nscratch = std::max(pre.nscratch, bd.nscratch); pre.muls = bd.muls; pre.redcs = bd.redcs;
-    Prog p; int rc = finalize_prog(ctx, m, pre, &p); if (rc) { hipFree(d_park); return rc; }
+    Prog p; int rc = finalize_prog(ctx, m, pre, &p); if (rc) return rc;
     itb = ctx->progs.emplace(kb, p).first;
   }
   int rc;
@@ -878,8 +898,6 @@ int sc_dgk_step4(sc_ctx* ctx, int mod, int cst_g, int cst_ginv, int l, const uin
                    mk_ext(alpha, 2, 2), mk_ext(alpha_tilde, 2, 2), mk_ext(c_out, m.nwords, m.nwords)};
     rc = run_vm(ctx, mod, itb->second, ex, 6, count);
   }
-  hipStreamSynchronize(ctx->stream);
-  hipFree(d_park);
   return rc;
 }
 

@@ -135,22 +135,16 @@ __global__ void __launch_bounds__(64) k_xgcd(const uint32_t* __restrict__ xin, u
   if (lane == 0) status[item] = ok ? 1 : 0;
 }
 
-// host launcher: n given as host words
-inline int launch_xgcd(hipStream_t stream, const uint32_t* x, uint32_t* out, const uint32_t* /*unused*/,
-                       const std::vector<uint32_t>& n, int nw, uint64_t count, int* d_status) {
-  uint32_t* d_n = nullptr;
-  if (hipMalloc((void**)&d_n, (size_t)nw * 4) != hipSuccess) return -1;
-  if (hipMemcpyAsync(d_n, n.data(), (size_t)nw * 4, hipMemcpyHostToDevice, stream) != hipSuccess) { hipFree(d_n); return -1; }
+// host launcher: d_n = modulus as canonical device words
+inline int launch_xgcd(hipStream_t stream, const uint32_t* x, uint32_t* out, const uint32_t* d_n, int nw, uint64_t count,
+                       int* d_status) {
   const int need = nw + 1;  // one spare word: r, s < 2n
   if (need <= 64) hipLaunchKernelGGL(k_xgcd<1>, dim3((unsigned)count), dim3(64), 0, stream, x, out, d_n, nw, d_status);
   else if (need <= 128) hipLaunchKernelGGL(k_xgcd<2>, dim3((unsigned)count), dim3(64), 0, stream, x, out, d_n, nw, d_status);
   else if (need <= 256) hipLaunchKernelGGL(k_xgcd<4>, dim3((unsigned)count), dim3(64), 0, stream, x, out, d_n, nw, d_status);
   else if (need <= 512) hipLaunchKernelGGL(k_xgcd<8>, dim3((unsigned)count), dim3(64), 0, stream, x, out, d_n, nw, d_status);
-  else { hipFree(d_n); return -2; }
-  hipError_t e = hipGetLastError();
-  hipStreamSynchronize(stream);
-  hipFree(d_n);
-  return e == hipSuccess ? 0 : -1;
+  else return -2;
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 // v_mad_u64_u32 issue-rate probe: 8 independent accumulator chains per lane, nothing else in the loop
