@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsc_amd.so")
+LIB_PATH = os.environ.get("SC_AMD_LIB", os.path.join(HERE, "libsc_amd.so"))  # override only for A/B experiments
 
 # every symbol include/sc_amd.h declares (tests check that the library exports all of them)
 SYMBOLS = [

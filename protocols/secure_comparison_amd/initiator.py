@@ -91,6 +91,53 @@ class Initiator:
         beta_lt_alpha_enc = Initiator.step_6(delta_a, delta_b_enc)
         return Initiator.step_7(zeta_1_enc, zeta_2_enc, r, l, beta_lt_alpha_enc, pai)
 
+    async def perform_secure_comparison_batch(self, x_enc: torch.Tensor, y_enc: torch.Tensor, draws=None,
+                                              source: str = "os", engine=None) -> torch.Tensor:
+        """B comparisons at once over the same four message exchanges, with batches on the wire as raw word arrays
+        (wire.py).  `draws` (batch.BatchDraws; Alice's fields) injects the randomness; otherwise it is drawn from the
+        OS CSPRNG and the randomizers come from device-side pools booted here (1 Paillier + (l+1) DGK per comparison,
+        SC/initiator.py:205-210 scaled by B).  x_enc, y_enc: [B][2nw] Paillier ciphertexts."""
+        from . import wire
+        from .randomness import random_bits_u64, random_permutations, uniform_below
+
+        if self.communicator is None:
+            raise ValueError("Communicator not properly initialized.")
+        self.session_id += 1
+        sid = self.session_id
+        got_p, got_d = wire.unpack_public_schemes(await self.communicator.recv(self.other_party, msg_id=f"schemes_batch_session_{sid}"), engine)
+        if self._scheme_paillier is None:
+            self._scheme_paillier = got_p
+        elif self._scheme_paillier != got_p:
+            raise ValueError("Readily available Paillier scheme and received Paillier scheme are different.")
+        if self._scheme_dgk is None:
+            self._scheme_dgk = got_d
+        elif self._scheme_dgk != got_d:
+            raise ValueError("Readily available DGK scheme and received DGK scheme are different.")
+        pai, dgk, l = self.scheme_paillier, self.scheme_dgk, self.l_maximum_bit_length
+        dev, count = x_enc.device, x_enc.shape[0]
+        if draws is None:
+            pai.boot_randomness_generation_batch(count, source)
+            dgk.boot_randomness_generation_batch((l + 1) * count, source)
+            u = dgk.public_key.u
+            rhos = uniform_below(u, (l + 1) * count, dev, source, nonzero=True).reshape(l + 1, count, -1)
+            r, delta_a = uniform_below(pai.public_key.n, count, dev, source), random_bits_u64(count, dev, source)
+            perm = random_permutations(count, l + 1, dev, source)
+        else:
+            r, delta_a, rhos, perm = draws.r, draws.delta_a, draws.rhos, draws.permutation
+        z_enc, plain = Initiator.step_1_batch(x_enc, y_enc, l, pai, r)
+        z_enc = pai.randomize_from_pool_batch(z_enc) if draws is None else pai.randomize_batch(z_enc, draws.rho_z)
+        await self.communicator.send(self.other_party, wire.pack_tensor(z_enc), msg_id=f"step_1_batch_session_{sid}")
+        d_enc, beta_enc = wire.unpack_many(await self.communicator.recv(self.other_party, msg_id=f"step_4b_batch_session_{sid}"), dev)
+        c_h = Initiator.step_4c_to_4h_batch(d_enc, beta_enc, plain, delta_a, dgk)
+        c = Initiator.step_4i_batch(c_h, dgk, rhos, perm, None if draws is None else draws.r_alice_dgk)
+        if draws is None:
+            lp1, _, nw = c.shape
+            c = dgk.randomize_from_pool_batch(c.reshape(lp1 * count, nw)).reshape(lp1, count, nw)
+        await self.communicator.send(self.other_party, wire.pack_tensor(c), msg_id=f"step_4i_batch_session_{sid}")
+        zeta_1, zeta_2, delta_b_enc = wire.unpack_many(await self.communicator.recv(self.other_party, msg_id=f"step_5_batch_session_{sid}"), dev)
+        blta = Initiator.step_6_batch(delta_a, delta_b_enc, pai)
+        return Initiator.step_7_batch(zeta_1, zeta_2, plain, l, blta, pai)
+
     async def receive_encryption_schemes(self, session_id: int = 1) -> None:
         """Receive Bob's public schemes; a pre-set scheme must match (SC/initiator.py:177-203)."""
         if self.communicator is None:

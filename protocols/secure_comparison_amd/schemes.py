@@ -153,6 +153,7 @@ class _Scheme:
     def __init__(self, engine=None) -> None:
         self._engine = engine
         self._pool: list[int] = []
+        self._batch_pool: torch.Tensor | None = None
 
     @property
     def engine(self):
@@ -192,6 +193,31 @@ class _Scheme:
 
     def shut_down(self) -> None:
         self._pool.clear()
+        self._batch_pool = None
+
+    # ---- device-resident randomizer pools for whole batches
+    def boot_randomness_generation_batch(self, amount: int, source: str = "os", generator=None) -> None:
+        """Pre-generate `amount` randomizers on the GPU and keep them as a device array (the batched analogue of
+        boot_randomness_generation: the expensive exponentiations happen ahead of the protocol run)."""
+        if amount <= 0:
+            return
+        fresh = self._generate_randomness_batch(amount, source, generator)
+        pool = getattr(self, "_batch_pool", None)
+        self._batch_pool = fresh if pool is None or pool.shape[0] == 0 else torch.cat([pool, fresh], dim=0)
+
+    def take_randomness_batch(self, amount: int, source: str = "os", generator=None) -> torch.Tensor:
+        pool = getattr(self, "_batch_pool", None)
+        have = 0 if pool is None else pool.shape[0]
+        if have < amount:
+            warnings.warn(WARN_OUT_OF_RANDOMNESS, UserWarning)
+            self.boot_randomness_generation_batch(amount - have, source, generator)
+            pool = self._batch_pool
+        out, self._batch_pool = pool[:amount], pool[amount:]
+        return out
+
+    def randomize_from_pool_batch(self, c: torch.Tensor) -> torch.Tensor:
+        """`.randomize()` for a batch: one modular product with pooled randomizers."""
+        return self.engine.modmul(self._ct_mod, c, self.take_randomness_batch(c.shape[0]))
 
     def __ne__(self, other: object) -> bool:
         return not self.__eq__(other)
@@ -384,6 +410,12 @@ class Paillier(_Scheme):
         rho = self.engine.upload([1 + secrets.randbelow(n - 1) for _ in range(amount)], self.mod_n.nwords)
         return self.engine.download(self.randomizer_batch(rho))
 
+    def _generate_randomness_batch(self, amount: int, source: str = "os", generator=None) -> torch.Tensor:
+        from .randomness import uniform_below
+
+        rho = uniform_below(self.public_key.n, amount, self.engine.device, source, generator, nonzero=True)
+        return self.randomizer_batch(rho)
+
     def _apply_randomness(self, value: int, randomness: int) -> int:
         return self._mul_values(value, randomness)
 
@@ -545,6 +577,11 @@ class DGK(_Scheme):
         ew = (self.randomizer_bits + 31) // 32
         r = self.engine.upload([secrets.randbits(self.randomizer_bits) for _ in range(amount)], ew)
         return self.engine.download(self.randomize_batch(None, r))
+
+    def _generate_randomness_batch(self, amount: int, source: str = "os", generator=None) -> torch.Tensor:
+        from .randomness import random_bits
+
+        return self.randomize_batch(None, random_bits(self.randomizer_bits, (amount,), self.engine.device, source, generator))
 
     def _apply_randomness(self, value: int, randomness: int) -> int:
         return self._mul_values(value, randomness)

@@ -345,3 +345,45 @@ def test_key_generation_and_fresh_keys(engine):
     assert dgk.decrypt(dgk.encrypt(5) + dgk.encrypt(-2)) == 3 and pai.decrypt(pai.encrypt(-7) * 3) == -21
     z_enc, r = Initiator.step_1(pai.unsafe_encrypt(3), pai.unsafe_encrypt(4), 8, pai)
     assert KeyHolder.step_2(z_enc, 8, pai)[0] == (4 - 3 + 256 + r) % pai.public_key.n
+
+
+def test_batched_interactive_protocol_on_gpu(engine, keys):
+    """Both players' perform_secure_comparison_batch over the in-memory transport with the binary wire format:
+    injected draws -> bit-exact vs the oracle; OS randomness + device pools -> correct bits, pools consumed exactly."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(__file__))
+    from _comm import DictionaryCommunicator
+    from protocols.secure_comparison_amd import Initiator, KeyHolder
+
+    sk, dgk = oracle_paillier(keys, 1024), oracle_dgk(keys, "dgk_1024_l16")
+    l, B, rbits = 16, 37, 400
+    _, _, bob_p, bob_d = _schemes(engine, sk, dgk, rbits)
+    rng = random.Random(8)
+    xs = [rng.randrange(1 << l) for _ in range(B)]
+    ys = [xs[i] if i % 3 == 0 else rng.randrange(1 << l) for i in range(B)]
+    x_enc = [sk.randomize(sk.enc_raw(x), 1 + rng.randrange(sk.n - 1)) for x in xs]
+    y_enc = [sk.randomize(sk.enc_raw(y), 1 + rng.randrange(sk.n - 1)) for y in ys]
+    drs = [o.draw(rng, l, sk, dgk, rbits) for _ in range(B)]
+    nw = bob_p.mod_n.nwords
+    draws = _draw_tensors(engine, drs, l, nw, (dgk.u.bit_length() + 31) // 32, (rbits + 31) // 32, engine.device)
+    tx, ty = engine.upload(x_enc, 2 * nw), engine.upload(y_enc, 2 * nw)
+    for use_draws in (True, False):
+        box = {}
+        alice = Initiator(l, DictionaryCommunicator(box), "bob")
+        bob = KeyHolder(l, DictionaryCommunicator(box), "alice", bob_p, bob_d)
+
+        async def go():
+            res, _ = await asyncio.gather(alice.perform_secure_comparison_batch(tx, ty, draws if use_draws else None, engine=engine),
+                                          bob.perform_secure_comparison_batch(draws if use_draws else None))
+            return res
+
+        with warnings.catch_warnings():
+            warnings.filterwarnings("error", ".*randomness", UserWarning)
+            got = engine.download(asyncio.run(go()))
+        assert [sk.dec_raw(v) for v in got] == [int(x <= y) for x, y in zip(xs, ys)]
+        if use_draws:
+            assert got == [o.compare(a, b, l, sk, dgk, d, True) for a, b, d in zip(x_enc, y_enc, drs)]
+        else:
+            for scheme in (alice.scheme_paillier, alice.scheme_dgk, bob_p, bob_d):
+                assert scheme._batch_pool.shape[0] == 0

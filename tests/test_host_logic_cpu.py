@@ -193,3 +193,60 @@ def test_batch_driver_layout_and_shuffle(world, use_crt):
     assert [eng.download(tr.c_sent[:, b])for b in range(B)] == [t["c_enc"] for t in traces]
     assert tr.delta_b.tolist() == [t["delta_b"] for t in traces]
     assert [osk.dec_raw(v) for v in eng.download(got)] == [int(x <= y) for x, y in zip(xs, ys)]
+
+
+def test_batched_interactive_protocol_and_wire_format(world):
+    """perform_secure_comparison_batch on both sides over the dictionary transport: (1) with injected draws it is
+    bit-identical to the oracle; (2) with OS randomness and device pools the decrypted results are right and the pools
+    are consumed exactly (1 + (l+1) per comparison for Alice, 3 + (l+1) for Bob)."""
+    osk, od, eng, bob_p, bob_d = world
+    rng = random.Random(31)
+    B = 5
+    xs = [rng.randrange(1 << L) for _ in range(B)]
+    ys = [xs[i] if i % 2 == 0 else rng.randrange(1 << L) for i in range(B)]
+    x_enc = [osk.randomize(osk.enc_raw(x), 1 + rng.randrange(osk.n - 1)) for x in xs]
+    y_enc = [osk.randomize(osk.enc_raw(y), 1 + rng.randrange(osk.n - 1)) for y in ys]
+    nw = bob_p.mod_n.nwords
+    tx, ty = eng.upload(x_enc, 2 * nw), eng.upload(y_enc, 2 * nw)
+    drs = [o.draw(rng, L, osk, od, 50) for _ in range(B)]
+    draws = make_draws(eng, drs, L, nw, (od.u.bit_length() + 31) // 32, 2)
+    for use_draws in (True, False):
+        box = {}
+        alice = Initiator(L, DictionaryCommunicator(box), "bob")
+        bob = KeyHolder(L, DictionaryCommunicator(box), "alice", bob_p, bob_d)
+
+        async def go():
+            res, _ = await asyncio.gather(alice.perform_secure_comparison_batch(tx, ty, draws if use_draws else None, engine=eng),
+                                          bob.perform_secure_comparison_batch(draws if use_draws else None))
+            return res
+
+        with warnings.catch_warnings():
+            warnings.filterwarnings("error", ".*randomness", UserWarning)
+            got = eng.download(asyncio.run(go()))
+        assert [osk.dec_raw(v) for v in got] == [int(x <= y) for x, y in zip(xs, ys)]
+        if use_draws:
+            assert got == [o.compare(a, b, L, osk, od, d, True) for a, b, d in zip(x_enc, y_enc, drs)]
+        else:
+            for scheme in (alice.scheme_paillier, alice.scheme_dgk, bob_p, bob_d):
+                assert scheme._batch_pool is not None and scheme._batch_pool.shape[0] == 0
+        assert alice.scheme_paillier == bob_p and alice.scheme_dgk == bob_d and not box
+
+
+def test_wire_and_randomness_helpers():
+    from protocols.secure_comparison_amd import randomness as R
+    from protocols.secure_comparison_amd import wire
+    from protocols.secure_comparison_amd.limbs import words_to_ints
+    import numpy as np
+
+    n = (1 << 1023) + 99
+    t = R.uniform_below(n, 300, "cpu", nonzero=True)
+    vals = words_to_ints(t.numpy().view(np.uint32))
+    assert all(0 < v < n for v in vals) and len(set(vals)) == 300
+    bits = R.random_bits(35, (4, 7), "cpu")
+    assert bits.shape == (4, 7, 2) and int((bits[..., 1].to(torch.int64) & 0xFFFFFFFF).max()) < 8
+    perms = R.random_permutations(6, 17, "cpu")
+    assert all(sorted(p.tolist()) == list(range(17)) for p in perms)
+    a, b, c = wire.unpack_many(wire.pack_many(t, perms, torch.tensor([1, 0], dtype=torch.uint8)))
+    assert torch.equal(a, t) and torch.equal(b, perms) and c.dtype == torch.uint8
+    with pytest.raises(ValueError):
+        wire.unpack_tensor(b"nope" + bytes(16))
