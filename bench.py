@@ -70,11 +70,12 @@ def synth_inputs(eng, l, alice_p, bob_p, bob_d, B, rbits, seed):
         w[:, 0] |= 1
         return w
 
-    x = torch.randint(0, 2 ** l, (B,), generator=g, device=dev, dtype=torch.int64)
-    y = torch.randint(0, 2 ** l, (B,), generator=g, device=dev, dtype=torch.int64)
+    xb = min(l, 62)  # int64 tensors: for l > 62 the synthetic inputs use the low 62 bits of the range
+    x = torch.randint(0, 2 ** xb, (B,), generator=g, device=dev, dtype=torch.int64)
+    y = torch.randint(0, 2 ** xb, (B,), generator=g, device=dev, dtype=torch.int64)
     sel = torch.arange(B, device=dev) % 8
     y = torch.where(sel == 0, x, y)
-    y = torch.where(sel == 1, torch.clamp(x + 1, max=2 ** l - 1), y)
+    y = torch.where(sel == 1, torch.clamp(x + 1, max=2 ** xb - 1), y)
 
     def small_words(v):
         w = torch.zeros((v.shape[0], nw), dtype=torch.int32, device=dev)

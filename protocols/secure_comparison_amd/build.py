@@ -24,10 +24,20 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", SRC, "-o", OUT]
+    # -pragma-unroll-threshold: the L = 27 limb-step loops (1458 multiply-adds per block) must be fully unrolled, otherwise
+    # the column registers are indexed dynamically and land in scratch memory (50x slower)
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-pragma-unroll-threshold=1000000",
+           SRC, "-o", OUT]
     if verbose:
         print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+    proc = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+    if proc.returncode != 0:
+        sys.stderr.write(proc.stderr)
+        raise subprocess.CalledProcessError(proc.returncode, cmd)
+    if "loop not unrolled" in proc.stderr:
+        # a partially unrolled limb loop indexes the column registers dynamically -> scratch memory -> ~50x slower
+        os.remove(OUT)
+        raise RuntimeError("hipcc did not fully unroll a limb loop (see -pragma-unroll-threshold in build.py)")
     return OUT
 
 

@@ -97,15 +97,18 @@ struct Grp {
     for (int i = 0; i < L; i++) T[i] = (MODE == 0) ? 0ull : (uint64_t)b[i];
 #pragma unroll 1
     for (int k = 0; k < G; k++) {
-      uint32_t av[L];
-      if constexpr (MODE == 0) {
+      // L <= 18: fetch the whole block of a-limbs up front (registers to spare).  Larger L: fetch limb by limb so the
+      // block does not pin another L registers (the L = 27 configurations otherwise spill into scratch).
+      constexpr bool PRELOAD = (L <= 18);
+      uint32_t av[PRELOAD ? L : 1];
+      if constexpr (MODE == 0 && PRELOAD) {
 #pragma unroll
         for (int l = 0; l < L; l++) av[l] = a_lds[k * L + l];
       }
 #pragma unroll
       for (int l = 0; l < L; l++) {
         if constexpr (MODE == 0) {
-          const uint32_t ai = av[l];
+          const uint32_t ai = PRELOAD ? av[PRELOAD ? l : 0] : a_lds[k * L + l];
 #pragma unroll
           for (int c = 0; c < L; c++) T[(l + c) % L] += (uint64_t)ai * b[c];
         }

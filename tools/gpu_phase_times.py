@@ -7,7 +7,10 @@ from protocols.secure_comparison_amd import DGK, Paillier, Initiator, KeyHolder
 from protocols.secure_comparison_amd.schemes import default_engine
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-l, pbits, rbits, fbw = 32, 2048, 400, int(sys.argv[2]) if len(sys.argv) > 2 else 13
+fbw = int(sys.argv[2]) if len(sys.argv) > 2 else 13
+pbits = int(sys.argv[3]) if len(sys.argv) > 3 else 2048
+l = int(sys.argv[4]) if len(sys.argv) > 4 else 32
+rbits = 400
 keys = json.load(open(bench.KEYS))
 pj, dj = keys[f"paillier_{pbits}"], keys[f"dgk_{pbits}_l{l}"]
 p, q = int(pj["p"], 16), int(pj["q"], 16)
@@ -19,7 +22,7 @@ x, y, x_enc, y_enc, draws = bench.synth_inputs(eng, l, alice_p, bob_p, bob_d, B,
 times = {}
 def timed(name, fn):
     torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize(); times[name] = times.get(name, 0) + (time.perf_counter() - t0) * 1e3; return r
-for it in range(2):
+for it in range(1 if pbits > 2048 else 2):
     times.clear()
     z_enc, a_plain = timed("A step1 (inv x, enc, 2 mul)", lambda: Initiator.step_1_batch(x_enc, y_enc, l, alice_p, draws.r))
     z_enc = timed("A randomize z (rho^N mod N^2)", lambda: alice_p.randomize_batch(z_enc, draws.rho_z))
