@@ -85,16 +85,16 @@ struct Grp {
   // -------------------------------------------------------------------------------------------
   // Montgomery product r = a * b / R mod n (lazily reduced: r < 2n, limbs < 2^29 + 2^7).
   //   a: S limbs in LDS (the group's staging area), b: this lane's L limbs.
-  //   MODE 0: full product.  MODE 1: reduction only (a ignored, computes b / R mod n).
+  //   MODE 0: full product.  MODE 3: square (a == b).  MODE 1: reduction only (a ignored, computes b / R mod n).
   //   MODE 2: like 1 and additionally collects the Montgomery quotient digits into quot[] (lane k
   //           keeps digits k*L..k*L+L-1); quot = -b / n mod R, which is how exact division is done.
   // -------------------------------------------------------------------------------------------
   template <int MODE>
   __device__ __forceinline__ void mont(uint32_t (&r)[L], const uint32_t* a_lds, const uint32_t (&b)[L],
-                                       uint32_t (&quot)[L]) const {
+                                       uint32_t (&quot)[L], const uint32_t* a2_lds = nullptr) const {
     uint64_t T[L];
 #pragma unroll
-    for (int i = 0; i < L; i++) T[i] = (MODE == 0) ? 0ull : (uint64_t)b[i];
+    for (int i = 0; i < L; i++) T[i] = (MODE == 0 || MODE == 3) ? 0ull : (uint64_t)b[i];
 #pragma unroll 1
     for (int k = 0; k < G; k++) {
       // L <= 18: fetch the whole block of a-limbs up front (registers to spare).  Larger L: fetch limb by limb so the
@@ -105,12 +105,25 @@ struct Grp {
 #pragma unroll
         for (int l = 0; l < L; l++) av[l] = a_lds[k * L + l];
       }
+      // MODE 3 (squaring, a == b): the L x L block a_k (x) a_j and its mirror a_j (x) a_k (computed by lane k at block
+      // step j) hold the same products, so every lane takes only the entries (l, c) with c > l of each of its blocks,
+      // doubled, plus the block diagonal c == l once: a diagonal entry of an off-diagonal block is then counted once
+      // here and once in the mirror block (= twice), a true square term a_i^2 (k == j) exactly once.  Every product
+      // still reaches its column before that column is consumed (it is added at a row <= its column index), the
+      // instruction stream is identical in all lanes, and the a*a part costs L(L+1)/2 instead of L^2 multiply-adds per
+      // block.  The doubled limbs 2*a_i are staged in LDS next to a_i (a2_lds), so the loop has no extra VALU work.
 #pragma unroll
       for (int l = 0; l < L; l++) {
         if constexpr (MODE == 0) {
           const uint32_t ai = PRELOAD ? av[PRELOAD ? l : 0] : a_lds[k * L + l];
 #pragma unroll
           for (int c = 0; c < L; c++) T[(l + c) % L] += (uint64_t)ai * b[c];
+        }
+        if constexpr (MODE == 3) {
+          const uint32_t ai = a_lds[k * L + l], ai2 = a2_lds[k * L + l];
+          T[(l + l) % L] += (uint64_t)ai * b[l];
+#pragma unroll
+          for (int c = l + 1; c < L; c++) T[(l + c) % L] += (uint64_t)ai2 * b[c];
         }
         uint32_t q = ((uint32_t)T[l] * n0inv) & LMASK;
         q = bcast0<G>(q);
@@ -143,6 +156,11 @@ struct Grp {
   __device__ __forceinline__ void mul(uint32_t (&r)[L], const uint32_t* a_lds, const uint32_t (&b)[L]) const {
     uint32_t dummy[L];
     mont<0>(r, a_lds, b, dummy);
+  }
+  // r = b * b / R mod n; a_lds / a2_lds must hold the limbs of b and of 2b (staged by the caller)
+  __device__ __forceinline__ void sqr(uint32_t (&r)[L], const uint32_t* a_lds, const uint32_t* a2_lds, const uint32_t (&b)[L]) const {
+    uint32_t dummy[L];
+    mont<3>(r, a_lds, b, dummy, a2_lds);
   }
   __device__ __forceinline__ void redc(uint32_t (&r)[L], const uint32_t (&b)[L]) const {
     uint32_t dummy[L];
@@ -215,6 +233,10 @@ struct Grp {
   __device__ __forceinline__ void stage(uint32_t* dst_lds /*group area*/, const uint32_t (&x)[L]) const {
 #pragma unroll
     for (int l = 0; l < L; l++) dst_lds[j * L + l] = x[l];
+  }
+  __device__ __forceinline__ void stage_doubled(uint32_t* dst_lds, const uint32_t (&x)[L]) const {
+#pragma unroll
+    for (int l = 0; l < L; l++) dst_lds[j * L + l] = x[l] << 1;
   }
   // copy S limbs (limb form, global) of one number into this lane's registers
   __device__ __forceinline__ void load_limbs(uint32_t (&x)[L], const uint32_t* __restrict__ src) const {

@@ -13,16 +13,18 @@ namespace sc {
 // the program and grid-strides over the batch.
 // ---------------------------------------------------------------------------------------------
 template <int G, int L>
-__global__ void __launch_bounds__(64, SC_VM_WAVES) k_vm(const VmArgs args) {
+__global__ void __launch_bounds__(64, (L > 18 ? 1 : SC_VM_WAVES)) k_vm(const VmArgs args) {
   using GT = Grp<G, L>;
   constexpr int S = GT::S, NG = GT::NG, SP = GT::SP, WP = GT::WP;
   __shared__ uint32_t s_a[NG * SP];            // per-group staging area for the LDS-side operand
+  __shared__ uint32_t s_a2[NG * SP];           // the same operand doubled (squarings only)
   __shared__ uint32_t s_w[NG * WP];            // per-group 32-bit-word scratch for format conversion
   __shared__ uint32_t s_c[VM_MAX_CONST * SP];  // modulus constants shared by all groups
 
   GT gp;
   gp.init(args.modctx, args.n0inv);
   uint32_t* const my_a = s_a + gp.g * SP;
+  uint32_t* const my_a2 = s_a2 + gp.g * SP;
   uint32_t* const my_w = s_w + gp.g * WP;
   for (int t = threadIdx.x; t < 2 * S; t += 64) s_c[(t / S) * SP + (t % S)] = args.modctx[S + t];
   for (int t = threadIdx.x; t < (int)args.nconst_extra * S; t += 64)
@@ -82,6 +84,7 @@ __global__ void __launch_bounds__(64, SC_VM_WAVES) k_vm(const VmArgs args) {
           __syncthreads();
           if (akind == AK_ACC) {
             gp.stage(my_a, acc);
+            gp.stage_doubled(my_a2, acc);
           } else if (akind == AK_EXTW) {
             const VmExt& e = args.ext[op.w1 & 0xf];
             const uint64_t flat = (uint64_t)op.w2 * args.count + idx;
@@ -99,7 +102,7 @@ __global__ void __launch_bounds__(64, SC_VM_WAVES) k_vm(const VmArgs args) {
           }
           __syncthreads();
           uint32_t r[L];
-          gp.mul(r, a_ptr, acc);
+          if (akind == AK_ACC) gp.sqr(r, a_ptr, my_a2, acc); else gp.mul(r, a_ptr, acc);
 #pragma unroll
           for (int l = 0; l < L; l++) acc[l] = r[l];
           break;

@@ -90,6 +90,7 @@ struct Prog {
   uint32_t* d_consts = nullptr;
   double muls_per_item = 0;   // Montgomery products (full) per item
   double redcs_per_item = 0;  // reduction-only passes per item
+  double sqrs_per_item = 0;   // squarings (a*a part costs L(L+1)/2 per block instead of L^2)
 };
 
 }  // namespace
@@ -180,7 +181,7 @@ struct Builder {
   std::vector<VmOp> ops;
   std::vector<int> consts;  // extra constant ids (LDS index = 2 + position)
   uint32_t nscratch = 1;
-  double muls = 0, redcs = 0;
+  double muls = 0, redcs = 0, sqrs = 0;
   void touch(uint32_t e) { nscratch = std::max(nscratch, e + 1); }
   void emit(uint32_t opc, uint32_t ak = 0, uint32_t imm = 0, uint32_t w1 = 0, uint32_t w2 = 0, uint32_t w3 = 0) {
     ops.push_back(VmOp{opc | (ak << 8) | (imm << 16), w1, w2, w3});
@@ -191,7 +192,7 @@ struct Builder {
     return 2 + (int)consts.size() - 1;
   }
   void mul_const(int lds_idx) { emit(OP_MUL, AK_CONST, 0, lds_idx); muls++; }
-  void sqr() { emit(OP_MUL, AK_ACC); muls++; }
+  void sqr() { emit(OP_MUL, AK_ACC); sqrs++; }
   void mul_tbl(uint32_t e) { touch(e); emit(OP_MUL, AK_TBL, 0, e); muls++; }
   void mul_tblsel(int extA, int bitA, int extB, int bitB, uint32_t e00, uint32_t e01, uint32_t e10, uint32_t e11) {
     touch(std::max(std::max(e00, e01), std::max(e10, e11)));
@@ -235,6 +236,7 @@ int finalize_prog(sc_ctx* ctx, const Mod& m, Builder& b, Prog* out) {
   p.nconst = (uint32_t)b.consts.size();
   p.muls_per_item = b.muls;
   p.redcs_per_item = b.redcs;
+  p.sqrs_per_item = b.sqrs;
   int rc = upload(ctx, b.ops.data(), b.ops.size() * sizeof(VmOp), (void**)&p.d_ops);
   if (rc) return rc;
   if (p.nconst) {
@@ -288,7 +290,8 @@ int run_vm(sc_ctx* ctx, int mod, const Prog& p, const VmExt* exts, int next, uin
   a.nconst_extra = p.nconst;
   a.nscratch = p.nscratch;
   for (int i = 0; i < next; i++) a.ext[i] = exts[i];
-  ctx->mac_counter += (double)count * (p.muls_per_item * 2.0 + p.redcs_per_item) * (double)m.S * m.S;
+  ctx->mac_counter += (double)count * ((p.muls_per_item * 2.0 + p.redcs_per_item + p.sqrs_per_item) * (double)m.S * m.S +
+                                        p.sqrs_per_item * (double)m.G * m.L * (m.L + 1) / 2.0);
   int rc = SC_ERR_UNSUPPORTED;
   int ci = 0;
 #define SC_CASE(GG, LL) if (m.G == GG && m.L == LL) rc = launch_vm_cfg<GG, LL>(ctx, a, ci); ci++;
@@ -888,7 +891,7 @@ int sc_dgk_step4(sc_ctx* ctx, int mod, int cst_g, int cst_ginv, int l, const uin
     Builder pre; const int cg = pre.use_const(cst_g);
     pre.loadt_const(cg); pre.stt(12);
     pre.ops.insert(pre.ops.end(), bd.ops.begin(), bd.ops.end());
-    pre.nscratch = std::max(pre.nscratch, bd.nscratch); pre.muls = bd.muls; pre.redcs = bd.redcs;
+    pre.nscratch = std::max(pre.nscratch, bd.nscratch); pre.muls = bd.muls; pre.redcs = bd.redcs; pre.sqrs = bd.sqrs;
     Prog p; int rc = finalize_prog(ctx, m, pre, &p); if (rc) return rc;
     itb = ctx->progs.emplace(kb, p).first;
   }
