@@ -204,9 +204,23 @@ def main() -> None:
         launch_s = ev0.elapsed_time(ev1) * 1e-3 / reps
         s32 = 2 * args.pbits // 32
         alg_macs = B * (args.pbits + -(-args.pbits // 5) + 30 + 1) * (2 * s32 * s32 + s32)
+        # ---- modexp/s for the two canonical shapes of SURVEY 8(d): P = Paillier randomizer, D = DGK fixed-base randomizer
+        d_exps = draws.r_alice_dgk.reshape((l + 1) * B, -1)
+        alice_d.randomize_batch(None, d_exps)
+        torch.cuda.synchronize()
+        ev0.record()
+        alice_d.randomize_batch(None, d_exps)
+        ev1.record()
+        torch.cuda.synchronize()
+        d_rate = d_exps.shape[0] / (ev0.elapsed_time(ev1) * 1e-3)
         peak = eng.peak_probe()
         lit = literal_macs_per_comparison(l, args.pbits, args.pbits, args.rbits)
         abytes = algorithmic_bytes_per_comparison(l, args.pbits, args.pbits, args.rbits)
+        # HBM traffic of the dominant launch from the committed PMC pass (rocprofv3 cannot run inside this process)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_dominant_kernel_traffic.json")
+        if os.path.exists(tpath) and B == 65536 and args.pbits == 2048 and l == 32:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch_uncorrected")
         out = {
             "metric": "secure comparisons/sec (l=%d, %d-bit keys)" % (l, args.pbits), "value": value, "unit": "comparisons/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -218,8 +232,13 @@ def main() -> None:
             "roofline": {"bound": "valu-int (v_mad_u64_u32 issue; neither HBM nor MFMA bound, SURVEY 8(d))",
                          "kernel": "k_vm<8,18>: Paillier randomizer rho^N mod N^2, B items in one launch",
                          "achieved": alg_macs / launch_s / 1e12, "peak": peak / 1e12, "unit": "T MAC/s (32x32->64)",
-                         "frac": alg_macs / launch_s / peak, "traffic": None, "launch_ms": launch_s * 1e3,
+                         "frac": alg_macs / launch_s / peak, "traffic": traffic,
+                         "traffic_note": "HBM bytes per launch, (FETCH_SIZE+WRITE_SIZE)*1024 from profiles/r01_pmc_summary.csv (same build, separate rocprofv3 --pmc passes; 4-8 B/lane accesses, FETCH_SIZE 2x correction not calibrated for them)",
+                         "launch_ms": launch_s * 1e3,
                          "algorithmic_macs_per_launch": alg_macs},
+            "modexp_per_s": {"P": B / launch_s, "D": d_rate,
+                             "shapes": "P: %d-bit base ^ %d-bit exponent mod %d-bit (rho^N mod N^2); D: fixed base, %d-bit exponent mod %d-bit (h^r mod n)"
+                                       % (args.pbits, args.pbits, 2 * args.pbits, args.rbits, args.pbits)},
             "roofline_whole_step": {"literal_macs_per_comparison": lit, "achieved": lit * value / world / 1e12, "peak": peak / 1e12,
                                     "unit": "T MAC/s per GPU", "frac": lit * value / world / peak,
                                     "executed_limb_macs_per_comparison": executed_macs / (B * args.steps),
@@ -242,7 +261,7 @@ def main() -> None:
                                  sum(t.numel() * t.element_size() for t in host_in) / B + r2.shape[-1] * 4}
         if not args.no_cpu_baseline:
             cores = min(os.cpu_count() or 1, 16)
-            sample = args.cpu_sample or 2 * cores
+            sample = args.cpu_sample or 64 * cores
             py = "/opt/conda/bin/python3.9" if os.path.exists("/opt/conda/bin/python3.9") else sys.executable
             try:
                 cp = subprocess.run([py, os.path.join(ROOT, "oracle", "cpu_baseline.py"), KEYS, f"paillier_{args.pbits}", dname,
