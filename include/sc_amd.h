@@ -105,6 +105,13 @@ int sc_paillier_encrypt_raw(sc_ctx* ctx, int mod_n2, int cst_n, const uint32_t* 
 int sc_paillier_l_mul(sc_ctx* ctx, int mod, int cst_k, const uint32_t* x_dptr, int x_words, uint32_t* out_dptr,
                       uint64_t count);
 
+/* out[i] = the x in [0, m_p m_q) with x = a_p[i] (mod m_p), x = a_q[i] (mod m_q):  a_q + m_q ((a_p - a_q) m_q^-1 mod m_p).
+ * Used by the key holder to recombine the CRT halves of decrypt (m_p = p, m_q = q) and of rho^N (m_p = p^2, m_q = q^2);
+ * identical integers to the reference's single-modulus pow_mod.  Constants: cst_k = m_q^-1 mod m_p and cst_negk =
+ * m_p - cst_k registered for mod_p, cst_mq = m_q registered for mod_full (= m_p m_q). */
+int sc_crt_combine(sc_ctx* ctx, int mod_p, int mod_full, int cst_k, int cst_negk, int cst_mq, const uint32_t* a_p_dptr,
+                   int a_p_words, const uint32_t* a_q_dptr, int a_q_words, uint32_t* out_dptr, uint64_t count);
+
 /* ---- plaintext-side word arithmetic of the two parties (HBM-bound helpers) ------------------------ */
 /* From r[count][nw] and the Paillier N: m1 = 2^l + r ([count][nw+1], SC/initiator.py:256), alpha = r mod 2^l
  * (:270), alpha_tilde = (r - N) mod 2^l (:373), rsmall = [r < (N-1)/2] (:289, :559), rshift = r >> l (:562).

@@ -171,6 +171,13 @@ __global__ void __launch_bounds__(64, (L > 18 ? 1 : SC_VM_WAVES)) k_vm(const VmA
           if (live && flat < e.limit) gp.store_limbs((uint32_t*)e.ptr + flat * e.stride, acc);
           break;
         }
+        case OP_ADDT: {
+          uint32_t t[L];
+          gp.load_limbs(t, my_tbl + (uint64_t)imm * S);
+#pragma unroll
+          for (int l = 0; l < L; l++) acc[l] += t[l];
+          break;
+        }
         case OP_ADD1: {
           acc[0] += (gp.j == 0) ? 1u : 0u;
           break;

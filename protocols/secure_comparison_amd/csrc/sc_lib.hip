@@ -112,6 +112,7 @@ struct sc_ctx {
   std::map<int, int> occ_cache;  // config index -> blocks per CU
   std::map<int, std::pair<void*, size_t>> tmp;          // grow-only temporaries, reused across calls (same stream => ordered)
   std::map<std::vector<uint32_t>, uint32_t*> nwords_cache;  // device copy of {n, (n-1)/2} for the plain-word kernels
+  std::map<int, int> kred_cache;                            // mod -> constant id of 2^(32 nwords) (wide-operand reduction)
 };
 
 namespace {
@@ -157,7 +158,7 @@ int tmp_buf(sc_ctx* ctx, int slot, size_t bytes, void** out) {
   *out = e.first;
   return SC_OK;
 }
-enum TmpSlot { TMP_PARK = 1, TMP_XGCD_STATUS = 2, TMP_INV_BASE = 16 /* + 2*depth, + 2*depth+1 */ };
+enum TmpSlot { TMP_PARK = 1, TMP_XGCD_STATUS = 2, TMP_CRT = 3, TMP_INV_BASE = 16 /* + 2*depth, + 2*depth+1 */ };
 
 // device copy of n | (n-1)/2 as canonical words (plain-word kernels)
 int device_n_half(sc_ctx* ctx, const uint32_t* n_hptr, int nw, uint32_t** out) {
@@ -221,6 +222,7 @@ struct Builder {
   void loadt_fbt(int ext, uint32_t bitpos, uint32_t width, uint32_t win) { emit(OP_LOADT, AK_FBT, 0, ext | (bitpos << 4) | (width << 24), win); }
   void loadt_extl(int ext, uint32_t off = 0) { emit(OP_LOADT, AK_EXTL, 0, ext, off); }
   void stt(uint32_t e) { touch(e); emit(OP_STT, 0, e); }
+  void addt(uint32_t e) { touch(e); emit(OP_ADDT, 0, e); }
   void redc() { emit(OP_REDC); redcs++; }
   void storew(int ext, uint32_t off = 0) { emit(OP_STOREW, 0, 0, ext, off); }
   void storel(int ext, uint32_t off = 0) { emit(OP_STOREL, 0, 0, ext, off); }
@@ -476,16 +478,14 @@ namespace {
 // Montgomery form of 2^(32 * nwords): multiplying by it shifts a residue up by one operand width
 int get_const_kred(sc_ctx* ctx, int mod, int* out_cid) {
   const Mod& m = ctx->mods[mod];
-  std::string key = "kred:" + std::to_string(mod);
-  static std::map<std::pair<sc_ctx*, int>, int> cache;
-  auto it = cache.find({ctx, mod});
-  if (it != cache.end()) { *out_cid = it->second; return SC_OK; }
+  auto it = ctx->kred_cache.find(mod);
+  if (it != ctx->kred_cache.end()) { *out_cid = it->second; return SC_OK; }
   Big one(m.nwords, 0); one[0] = 1;
   Big v = big_shl_mod(one, m.n, 32 * m.nwords);
   int cid;
   int rc = sc_const_create(ctx, mod, v.data(), m.nwords, &cid);
   if (rc) return rc;
-  cache[{ctx, mod}] = cid;
+  ctx->kred_cache[mod] = cid;
   *out_cid = cid;
   return SC_OK;
 }
@@ -902,6 +902,51 @@ int sc_dgk_step4(sc_ctx* ctx, int mod, int cst_g, int cst_ginv, int l, const uin
     rc = run_vm(ctx, mod, itb->second, ex, 6, count);
   }
   return rc;
+}
+
+int sc_crt_combine(sc_ctx* ctx, int mod_p, int mod_full, int cst_k, int cst_negk, int cst_mq, const uint32_t* a_p, int a_p_words,
+                   const uint32_t* a_q, int a_q_words, uint32_t* out, uint64_t count) {
+  if (ctx && count == 0) return SC_OK;
+  if (!valid_mod(ctx, mod_p) || !valid_mod(ctx, mod_full) || !a_p || !a_q || !out || a_p_words <= 0 || a_q_words <= 0)
+    return fail(ctx, SC_ERR_ARG, "sc_crt_combine: bad argument");
+  for (int c : {cst_k, cst_negk, cst_mq})
+    if (c < 0 || c >= (int)ctx->consts.size()) return fail(ctx, SC_ERR_ARG, "sc_crt_combine: bad constant");
+  if (ctx->consts[cst_k].mod != mod_p || ctx->consts[cst_negk].mod != mod_p || ctx->consts[cst_mq].mod != mod_full)
+    return fail(ctx, SC_ERR_ARG, "sc_crt_combine: constant registered for another modulus");
+  const Mod& mp = ctx->mods[mod_p];
+  const Mod& mf = ctx->mods[mod_full];
+  uint32_t* d_t;
+  { int rc0 = tmp_buf(ctx, TMP_CRT, (size_t)count * mp.nwords * 4, (void**)&d_t); if (rc0) return rc0; }
+  std::string k1 = "crt1:" + std::to_string(mod_p) + ":" + std::to_string(cst_k) + ":" + std::to_string(cst_negk) + ":" + std::to_string(a_p_words) + ":" + std::to_string(a_q_words);
+  auto it1 = ctx->progs.find(k1);
+  if (it1 == ctx->progs.end()) {
+    Builder bd; const int ck = bd.use_const(cst_k), cn = bd.use_const(cst_negk);
+    int kc = -1;
+    if (a_p_words > mp.nwords || a_q_words > mp.nwords) { int cid; int rc = get_const_kred(ctx, mod_p, &cid); if (rc) return rc; kc = bd.use_const(cid); }
+    if (a_p_words > mp.nwords) emit_load_reduced(ctx, mp, bd, 0, a_p_words, kc); else bd.loadw(0, 0, 0, a_p_words);
+    bd.mul_const(ck); bd.stt(0);                                     // a_p * k
+    if (a_q_words > mp.nwords) emit_load_reduced(ctx, mp, bd, 1, a_q_words, kc); else bd.loadw(1, 0, 0, a_q_words);
+    bd.mul_const(cn); bd.addt(0);                                    // + a_q * (m_p - k)  = (a_p - a_q) * m_q^-1  (mod m_p)
+    bd.storew(2); bd.end();
+    Prog p; int rc = finalize_prog(ctx, mp, bd, &p); if (rc) return rc;
+    it1 = ctx->progs.emplace(k1, p).first;
+  }
+  {
+    VmExt ex[3] = {mk_ext(a_p, a_p_words, a_p_words), mk_ext(a_q, a_q_words, a_q_words), mk_ext(d_t, mp.nwords, mp.nwords)};
+    int rc = run_vm(ctx, mod_p, it1->second, ex, 3, count); if (rc) return rc;
+  }
+  std::string k2 = "crt2:" + std::to_string(mod_full) + ":" + std::to_string(cst_mq) + ":" + std::to_string(mp.nwords) + ":" + std::to_string(a_q_words);
+  auto it2 = ctx->progs.find(k2);
+  if (it2 == ctx->progs.end()) {
+    Builder bd; const int cm = bd.use_const(cst_mq);
+    bd.loadw(0, 0, 0, mp.nwords); bd.mul_const(cm);                  // m_q * t   (< m_p m_q: exact)
+    bd.addw(1, 0, 0, a_q_words);                                     // + a_q
+    bd.storew(2); bd.end();
+    Prog p; int rc = finalize_prog(ctx, mf, bd, &p); if (rc) return rc;
+    it2 = ctx->progs.emplace(k2, p).first;
+  }
+  VmExt ex[3] = {mk_ext(d_t, mp.nwords, mp.nwords), mk_ext(a_q, a_q_words, a_q_words), mk_ext(out, mf.nwords, mf.nwords)};
+  return run_vm(ctx, mod_full, it2->second, ex, 3, count);
 }
 
 int sc_peak_probe(sc_ctx* ctx, double* out_mac_per_s) {

@@ -24,6 +24,7 @@ enum VmOpcode : uint32_t {
   OP_QUOT = 11,      // ACC = ACC / n exactly (ACC must be an exact multiple of n, value < R)
   OP_STOREL = 12,    // limb-form store of ACC to ext[w1] at off w2 (ext stride = S)
   OP_CANON = 13,     // ACC = canonical(ACC)
+  OP_ADDT = 14,      // ACC += scratch[imm]  (lazy limb-wise add)
 };
 
 enum VmAKind : uint32_t {

@@ -222,6 +222,18 @@ class Engine:
                                                self._ptr(out), count))
         return out
 
+    def crt_combine(self, mod_p: Modulus, mod_full: Modulus, mq: int, a_p: torch.Tensor, a_q: torch.Tensor,
+                    out: torch.Tensor | None = None) -> torch.Tensor:
+        """x with x = a_p (mod m_p), x = a_q (mod m_q), m_p m_q = mod_full.n (CRT recombination on the GPU)."""
+        count = a_p.shape[0]
+        out = self.empty(count, mod_full.nwords) if out is None else out
+        k = pow(mq, -1, mod_p.n)
+        self._sync_stream()
+        self._check(self.lib.sc_crt_combine(self.ctx, mod_p.id, mod_full.id, self.constant(mod_p, k), self.constant(mod_p, mod_p.n - k),
+                                            self.constant(mod_full, mq), self._ptr(a_p), a_p.shape[-1], self._ptr(a_q), a_q.shape[-1],
+                                            self._ptr(out), count))
+        return out
+
     def plain_alice(self, r: torch.Tensor, n: int, l: int):
         count, nw = r.shape
         m1 = self.empty(count, nw + 1)

@@ -339,8 +339,6 @@ class Paillier(_Scheme):
                     # randomizer: rho^N mod p^2 = ((rho mod p)^(q mod (p-1)) mod p)^p mod p^2   (x^p mod p^2 depends on x mod p only)
                     "e_small": other % (pr - 1),
                 }
-            crt["q_inv_p"] = pow(q, -1, p)
-            crt["q2_inv_p2"] = pow(q * q, -1, p * p)
             self._crt = crt
         return self._crt
 
@@ -353,28 +351,7 @@ class Paillier(_Scheme):
             c = crt[name]
             y = e.modexp_shared(c["m1"], rho, c["e_small"])                 # (rho mod p)^(q mod p-1) mod p  (wide input reduced)
             parts[name] = e.modexp_shared(c["m2"], torch.nn.functional.pad(y, (0, c["m2"].nwords - y.shape[-1])), pr)
-        return self._crt_combine(parts["p"], parts["q"], p * p, q * q, crt["p"]["m2"], crt["q2_inv_p2"], self.mod_n2)
-
-    def _crt_combine(self, a_p, a_q, mp_int, mq_int, mod_p, mq_inv_mp, mod_full):
-        """x = a_q + mq * ((a_p - a_q) * mq^-1 mod mp), all on the GPU.  (a_p - a_q) is formed as a_p + (mp - a_q mod mp)."""
-        e = self.engine
-        wp = mod_p.nwords
-        # t = (a_p - a_q) * mq_inv mod mp   computed as a_p*mq_inv - a_q*mq_inv = a_p*k + a_q*(mp - k)   (a_q may exceed mp: reduced by the wide load)
-        k = mq_inv_mp % mp_int
-        t1 = e.modmul_const(mod_p, a_p, k)
-        aq_red = e.modexp_shared(mod_p, a_q, 1)                                # a_q mod mp
-        t2 = e.modmul_const(mod_p, aq_red, (mp_int - k) % mp_int)
-        # t = t1 + t2 mod mp : use (1 + t1/x)... simpler: multiply-add identity  t1 + t2 = (t1 * 1 + t2) -> done via modmul with packed trick below
-        t = self._modadd(mod_p, t1, t2, mp_int)
-        # x = a_q + mq * t  (< mp*mq): mq*t mod (mp*mq) is exact, then one modular addition in the full modulus
-        wf = mod_full.nwords
-        tq = e.modmul_const(mod_full, torch.nn.functional.pad(t, (0, wf - wp)), mq_int)
-        return self._modadd(mod_full, tq, torch.nn.functional.pad(a_q, (0, wf - a_q.shape[-1])), mp_int * mq_int)
-
-    def _modadd(self, mod, a: torch.Tensor, b: torch.Tensor, m_int: int) -> torch.Tensor:
-        """(a + b) mod m for canonical residues: word-wise add with carry (torch, HBM-bound plumbing), then reduce on the GPU."""
-        wide = _add_words(a, b)                      # [count][nw+1], value < 2m
-        return self.engine.modexp_shared(mod, wide, 1)   # wide-operand reduction mod m
+        return e.crt_combine(crt["p"]["m2"], self.mod_n2, q * q, parts["p"], parts["q"])
 
     def _crt_decrypt(self, c: torch.Tensor) -> torch.Tensor:
         e, sk, crt = self.engine, self.secret_key, self._crt_setup()
@@ -384,7 +361,7 @@ class Paillier(_Scheme):
             cc = crt[name]
             x = e.modexp_shared(cc["m2"], c, pr - 1)                       # c^(p-1) mod p^2 (wide input reduced)
             ms[name] = e.paillier_l_mul(cc["m1"], cc["h"], x)              # L_p(x) * h_p mod p
-        return self._crt_combine(ms["p"], ms["q"], p, q, crt["p"]["m1"], crt["q_inv_p"], self.mod_n)
+        return e.crt_combine(crt["p"]["m1"], self.mod_n, q, ms["p"], ms["q"])
 
     # ---- single-ciphertext API of the reference
     def _unsafe_encrypt_raw_value(self, m: int) -> int:
@@ -418,22 +395,6 @@ class Paillier(_Scheme):
 
     def _apply_randomness(self, value: int, randomness: int) -> int:
         return self._mul_values(value, randomness)
-
-
-def _add_words(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """Word-wise a + b with carry propagation -> [count][nw+1] (torch int64 arithmetic on the device)."""
-    nw = max(a.shape[-1], b.shape[-1])
-    a64 = torch.nn.functional.pad(a, (0, nw - a.shape[-1])).to(torch.int64) & 0xFFFFFFFF
-    b64 = torch.nn.functional.pad(b, (0, nw - b.shape[-1])).to(torch.int64) & 0xFFFFFFFF
-    s = a64 + b64                                    # < 2^33 per word
-    out = torch.zeros((s.shape[0], nw + 1), dtype=torch.int64, device=s.device)
-    carry = torch.zeros((s.shape[0],), dtype=torch.int64, device=s.device)
-    for k in range(nw):
-        v = s[:, k] + carry
-        out[:, k] = v & 0xFFFFFFFF
-        carry = v >> 32
-    out[:, nw] = carry
-    return out.to(torch.int32)
 
 
 # =====================================================================================================

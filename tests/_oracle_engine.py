@@ -100,6 +100,10 @@ class OracleEngine:
     def paillier_l_mul(self, mod, k, x, out=None):
         return self.upload([((v % (mod.n * mod.n)) - 1) // mod.n * k % mod.n for v in self._ints(x)], mod.nwords)
 
+    def crt_combine(self, mod_p, mod_full, mq, a_p, a_q, out=None):
+        k = pow(mq, -1, mod_p.n)
+        return self.upload([(y + mq * ((x - y) * k % mod_p.n)) % mod_full.n for x, y in zip(self._ints(a_p), self._ints(a_q))], mod_full.nwords)
+
     def plain_alice(self, r, n, l):
         rs = self._ints(r)
         nw = r.shape[-1]
