@@ -9,8 +9,9 @@
 // accumulator absorbs 2L <= 54 products (54 * 2^58 < 2^64) with NO carry handling; carries are
 // resolved once per column when it leaves the lane.
 //
-// Montgomery form: R = 2^(29*S); R > 2^38 * n for every configuration, so operands may stay in
-// [0, 2n) between multiplications (no conditional subtraction inside exponentiation loops).
+// Montgomery form: R = 2^(29*S) >= 2^8 * n for every modulus a configuration accepts (2^40 * n for the
+// 2048/4096-bit cases), so operands may stay in [0, 2n) between multiplications -- even [0, 4n) after a lazy
+// addition -- with no conditional subtraction inside exponentiation loops.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -112,6 +113,9 @@ struct Grp {
       // still reaches its column before that column is consumed (it is added at a row <= its column index), the
       // instruction stream is identical in all lanes, and the a*a part costs L(L+1)/2 instead of L^2 multiply-adds per
       // block.  The doubled limbs 2*a_i are staged in LDS next to a_i (a2_lds), so the loop has no extra VALU work.
+      // Column bound: a column lives L limb steps in a lane; it takes a q*n product (< 2^58) at each of them and a
+      // doubled a*a product (< 2^59) only while its position is >= the row index, i.e. at <= L/2 + 1 of them:
+      // (L + 2) 2^58 + L 2^58 <= 56 * 2^58 < 2^64 for L <= 27 -- the same bound as the general product (2L * 2^58).
 #pragma unroll
       for (int l = 0; l < L; l++) {
         if constexpr (MODE == 0) {
@@ -151,6 +155,22 @@ struct Grp {
       const uint64_t v = (uint64_t)r[0] + (((uint64_t)chi << 32) | clo);
       r[0] = (uint32_t)v & LMASK;
       r[1] += (uint32_t)(v >> W);
+    }
+  }
+  // One local carry pass plus the hand-over of the lane carry: brings limbs that grew by lazy additions (entries
+  // < 2^31) back to <= 2^29 + 1, so that the accumulator bounds of mont() hold for the next product.
+  __device__ __forceinline__ void renorm(uint32_t (&r)[L]) const {
+    uint32_t c = 0;
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+      const uint32_t v = r[l] + c;
+      r[l] = v & LMASK;
+      c = v >> W;
+    }
+    if constexpr (G > 1) {
+      const uint32_t v = r[0] + from_below(c);
+      r[0] = v & LMASK;
+      r[1] += v >> W;
     }
   }
   __device__ __forceinline__ void mul(uint32_t (&r)[L], const uint32_t* a_lds, const uint32_t (&b)[L]) const {

@@ -130,6 +130,7 @@ __global__ void __launch_bounds__(64, (L > 18 ? 1 : SC_VM_WAVES)) k_vm(const VmA
           for (int l = 0; l < L; l++) t[l] = ok ? t[l] : ((gp.j == 0 && l == 0) ? 1u : 0u);
 #pragma unroll
           for (int l = 0; l < L; l++) acc[l] = (opc == OP_LOADW) ? t[l] : acc[l] + t[l];
+          if (opc == OP_ADDW) gp.renorm(acc);
           break;
         }
         case OP_REDC: {
@@ -176,10 +177,12 @@ __global__ void __launch_bounds__(64, (L > 18 ? 1 : SC_VM_WAVES)) k_vm(const VmA
           gp.load_limbs(t, my_tbl + (uint64_t)imm * S);
 #pragma unroll
           for (int l = 0; l < L; l++) acc[l] += t[l];
+          gp.renorm(acc);
           break;
         }
         case OP_ADD1: {
           acc[0] += (gp.j == 0) ? 1u : 0u;
+          gp.renorm(acc);
           break;
         }
         case OP_SUB1: {

@@ -387,3 +387,24 @@ def test_batched_interactive_protocol_on_gpu(engine, keys):
         else:
             for scheme in (alice.scheme_paillier, alice.scheme_dgk, bob_p, bob_d):
                 assert scheme._batch_pool.shape[0] == 0
+
+
+@pytest.mark.parametrize("bits", [512, 1024, 1536, 2048, 3072, 4096, 6144, 8192])
+def test_worst_case_limbs(engine, bits):
+    """Moduli and operands whose 29-bit limbs are all ones (n = 2^bits - c, a = n - 1, n - 2, 2^k - 1): the largest column
+    sums the lazy 64-bit accumulators can see, in every kernel configuration, through products, squarings and the
+    wide-operand reduction."""
+    n = (1 << bits) - 1
+    while n % 3 == 0 or n % 5 == 0 or n % 2 == 0:
+        n -= 2
+    mod = engine.modulus(n)
+    vals = [n - 1, n - 2, (1 << (bits - 1)) - 1, (n - 1) // 2, n - (1 << 29), 1, 0, (1 << (bits - 3)) + 1]
+    t = engine.upload(vals, mod.nwords)
+    e = (1 << 200) - 1          # all-ones exponent: squarings and products alternate densely
+    assert engine.download(engine.modexp_shared(mod, t, e)) == [pow(v, e, n) for v in vals]
+    assert engine.download(engine.modmul(mod, t, t)) == [v * v % n for v in vals]
+    assert engine.download(engine.modexp_shared(mod, t, 2, mul_into=t)) == [pow(v, 3, n) for v in vals]
+    wide = [(1 << (2 * bits)) - 1 - 977 * i for i in range(8)]     # all-ones operand twice as wide as the modulus
+    assert engine.download(engine.modexp_shared(mod, engine.upload(wide, 2 * mod.nwords), 3)) == [pow(w, 3, n) for w in wide]
+    ev = [(1 << 67) - 1, (1 << 66) + 12345, 7, 1, 0, (1 << 35) - 1, 3, 2]
+    assert engine.download(engine.modexp_var(mod, t, engine.upload(ev, 3), 67)) == [pow(v, x, n) for v, x in zip(vals, ev)]
