@@ -279,6 +279,7 @@ int launch_vm_cfg(sc_ctx* ctx, const VmArgs& a, int cfg_index) {
 
 int run_vm(sc_ctx* ctx, int mod, const Prog& p, const VmExt* exts, int next, uint64_t count, const uint32_t* fbt_rows = nullptr) {
   if (count == 0) return SC_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));  // the caller may have switched the current device since sc_ctx_create
   const Mod& m = ctx->mods[mod];
   VmArgs a;
   memset(&a, 0, sizeof a);
@@ -621,7 +622,6 @@ int sc_fixedbase_pow(sc_ctx* ctx, int fbt, const uint32_t* e, int ewords, const 
   if (!ctx || fbt < 0 || fbt >= (int)ctx->fbts.size() || !e || !out || ewords <= 0) return fail(ctx, SC_ERR_ARG, "sc_fixedbase_pow: bad argument");
   const Fbt& f = ctx->fbts[fbt];
   const Mod& m = ctx->mods[f.mod];
-  if (32 * ewords < f.exp_bits - 31 && false) return SC_ERR_ARG;
   std::string key = "fbp:" + std::to_string(fbt) + ":" + std::to_string(mul_into ? 1 : 0);
   auto it = ctx->progs.find(key);
   if (it == ctx->progs.end()) {
