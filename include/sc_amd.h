@@ -100,6 +100,10 @@ int sc_modinv(sc_ctx* ctx, int mod, const uint32_t* x_dptr, uint32_t* out_dptr, 
  * m: [count][m_words], any m < 2^(32 m_words) (reduction mod N is implicit). */
 int sc_paillier_encrypt_raw(sc_ctx* ctx, int mod_n2, int cst_n, const uint32_t* m_dptr, int m_words,
                             uint32_t* out_dptr, uint64_t count);
+/* out[i] = 1 - m[i] * N mod N^2 = [[-m]] = [[m]]^-1: lets the Initiator form ([[r div 2^l]])^-1 of SC/initiator.py:559-563 without
+ * a modular inversion. */
+int sc_paillier_encrypt_raw_neg(sc_ctx* ctx, int mod_n2, int cst_n, const uint32_t* m_dptr, int m_words,
+                                uint32_t* out_dptr, uint64_t count);
 /* out[i] = ((x[i] - 1) / n) * k mod n for x[i] = 1 (mod n), x: [count][x_words]: the L function and the
  * mu multiplication of Paillier.decrypt (SC/keyholder.py:195).  mod = N (or p, q for CRT), cst_k = mu. */
 int sc_paillier_l_mul(sc_ctx* ctx, int mod, int cst_k, const uint32_t* x_dptr, int x_words, uint32_t* out_dptr,

@@ -68,8 +68,7 @@ def secure_comparison_batch(x_enc: torch.Tensor, y_enc: torch.Tensor, l: int, al
                                            torch.cat([draws.rho_zeta_1, draws.rho_zeta_2, draws.rho_delta_b], dim=0))
         zeta_1_enc, zeta_2_enc, delta_b_enc = rnd[:count], rnd[count:2 * count], rnd[2 * count:]
     # Alice: steps 6, 7
-    blta = Initiator.step_6_batch(draws.delta_a, delta_b_enc, alice_paillier)
-    result = Initiator.step_7_batch(zeta_1_enc, zeta_2_enc, a_plain, l, blta, alice_paillier)
+    result = Initiator.step_6_7_batch(draws.delta_a, delta_b_enc, zeta_1_enc, zeta_2_enc, a_plain, l, alice_paillier)
     if trace is not None:
         trace.z_enc, trace.z, trace.d_enc, trace.beta_enc = z_enc, b_plain.z, d_enc, beta_enc
         trace.c_step4h, trace.c_sent, trace.delta_b = c_h, c_sent, delta_b

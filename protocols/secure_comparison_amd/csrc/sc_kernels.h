@@ -172,6 +172,17 @@ __global__ void __launch_bounds__(64, ((L > 18 || G == 16) ? 1 : SC_VM_WAVES)) k
           if (live && flat < e.limit) gp.store_limbs((uint32_t*)e.ptr + flat * e.stride, acc);
           break;
         }
+        case OP_NEG: {
+          gp.canonical(acc);
+          uint32_t t[L];
+#pragma unroll
+          for (int l = 0; l < L; l++) t[l] = gp.n[l];
+          gp.normalize(t, acc);   // n - ACC in (0, n]
+          gp.canonical(t);        // n -> 0
+#pragma unroll
+          for (int l = 0; l < L; l++) acc[l] = t[l];
+          break;
+        }
         case OP_ADDT: {
           uint32_t t[L];
           gp.load_limbs(t, my_tbl + (uint64_t)imm * S);

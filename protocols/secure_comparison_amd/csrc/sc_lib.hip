@@ -669,17 +669,27 @@ int sc_modexp_var(sc_ctx* ctx, int mod, const uint32_t* x, const uint32_t* e, in
   return run_vm(ctx, mod, it->second, ex, 4, count, f ? f->d_rows : nullptr);
 }
 
+static int paillier_encrypt_raw_impl(sc_ctx* ctx, int mod_n2, int cst_n, const uint32_t* mwords, int m_words, uint32_t* out, uint64_t count, bool negate);
+
 int sc_paillier_encrypt_raw(sc_ctx* ctx, int mod_n2, int cst_n, const uint32_t* mwords, int m_words, uint32_t* out, uint64_t count) {
+  return paillier_encrypt_raw_impl(ctx, mod_n2, cst_n, mwords, m_words, out, count, false);
+}
+int sc_paillier_encrypt_raw_neg(sc_ctx* ctx, int mod_n2, int cst_n, const uint32_t* mwords, int m_words, uint32_t* out, uint64_t count) {
+  return paillier_encrypt_raw_impl(ctx, mod_n2, cst_n, mwords, m_words, out, count, true);
+}
+
+static int paillier_encrypt_raw_impl(sc_ctx* ctx, int mod_n2, int cst_n, const uint32_t* mwords, int m_words, uint32_t* out, uint64_t count, bool negate) {
   if (ctx && count == 0) return SC_OK;  // empty batch: nothing to do (pointers may be null)
   if (!valid_mod(ctx, mod_n2) || cst_n < 0 || cst_n >= (int)ctx->consts.size() || ctx->consts[cst_n].mod != mod_n2 || !mwords || !out || m_words <= 0)
     return fail(ctx, SC_ERR_ARG, "sc_paillier_encrypt_raw: bad argument");
   const Mod& m = ctx->mods[mod_n2];
   if (m_words > m.nwords) return fail(ctx, SC_ERR_ARG, "sc_paillier_encrypt_raw: plaintext wider than N^2");
-  std::string key = "penc:" + std::to_string(mod_n2) + ":" + std::to_string(cst_n) + ":" + std::to_string(m_words);
+  std::string key = std::string(negate ? "pencn:" : "penc:") + std::to_string(mod_n2) + ":" + std::to_string(cst_n) + ":" + std::to_string(m_words);
   auto it = ctx->progs.find(key);
   if (it == ctx->progs.end()) {
     Builder bd; int c = bd.use_const(cst_n);
     bd.loadw(0, 0, 0, m_words); bd.mul_const(c);   // m * (N R) / R = m N  (mod N^2)
+    if (negate) bd.emit(OP_NEG);                   // -m N: the inverse ciphertext (1 + mN)^-1 = 1 - mN (mod N^2)
     bd.emit(OP_ADD1); bd.storew(1); bd.end();
     Prog p; int rc = finalize_prog(ctx, m, bd, &p); if (rc) return rc;
     it = ctx->progs.emplace(key, p).first;

@@ -25,6 +25,7 @@ enum VmOpcode : uint32_t {
   OP_STOREL = 12,    // limb-form store of ACC to ext[w1] at off w2 (ext stride = S)
   OP_CANON = 13,     // ACC = canonical(ACC)
   OP_ADDT = 14,      // ACC += scratch[imm]  (lazy limb-wise add)
+  OP_NEG = 15,       // ACC = (n - ACC) mod n, exact limbs
 };
 
 enum VmAKind : uint32_t {

@@ -214,6 +214,15 @@ class Engine:
                                                      m.shape[-1], self._ptr(out), count))
         return out
 
+    def paillier_encrypt_raw_neg(self, mod_n2: Modulus, n: int, m: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        """[[-m]] = 1 - m N mod N^2 (the inverse of paillier_encrypt_raw's result, without an inversion)."""
+        count = m.shape[0]
+        out = self.empty(count, mod_n2.nwords) if out is None else out
+        self._sync_stream()
+        self._check(self.lib.sc_paillier_encrypt_raw_neg(self.ctx, mod_n2.id, self.constant(mod_n2, n), self._ptr(m),
+                                                         m.shape[-1], self._ptr(out), count))
+        return out
+
     def paillier_l_mul(self, mod: Modulus, k: int, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
         count = x.shape[0]
         out = self.empty(count, mod.nwords) if out is None else out

@@ -313,3 +313,21 @@ class Initiator:
         zeta = torch.where((plain.r_small != 0).reshape(-1, 1), zeta_1_enc, zeta_2_enc).contiguous()
         t = scheme_paillier.add_batch(scheme_paillier.encrypt_raw_batch(plain.r_shift), beta_lt_alpha_enc)
         return scheme_paillier.add_batch(zeta, scheme_paillier.neg_batch(t))
+
+    @staticmethod
+    def step_6_7_batch(delta_a: torch.Tensor, delta_b_enc: torch.Tensor, zeta_1_enc: torch.Tensor, zeta_2_enc: torch.Tensor,
+                       plain: AlicePlain, l: int, scheme_paillier: Paillier) -> torch.Tensor:
+        """Steps 6 and 7 together with ONE inversion pass instead of two, yielding the same residues:
+        [[x<=y]] = [[zeta]] * ([[r div 2^l]] * [[beta<alpha]])^-1 with [[beta<alpha]] = [[delta_B]] (delta_A = 1) or
+        [[1]] [[delta_B]]^-1 (delta_A = 0) equals [[zeta]] * D * [[-(r div 2^l) - (1 - delta_A)]] with D = [[delta_B]]^-1
+        (delta_A = 1) or [[delta_B]] (delta_A = 0), because [[a]] [[b]] = [[a + b]] holds exactly for unrandomized
+        g = N + 1 encryptions (SC/initiator.py:529-531, 558-563)."""
+        e, pai = scheme_paillier.engine, scheme_paillier
+        n = pai.public_key.n
+        sel = (delta_a != 0).reshape(-1, 1)
+        d_factor = torch.where(sel, pai.neg_batch(delta_b_enc), delta_b_enc).contiguous()
+        neg_r = pai.encrypt_raw_neg_batch(plain.r_shift)                                   # [[-(r div 2^l)]]
+        neg_r_1 = e.modmul_const(pai.mod_n2, neg_r, (1 - n) % (n * n))                     # * [[-1]]
+        corr = torch.where(sel, neg_r, neg_r_1).contiguous()
+        zeta = torch.where((plain.r_small != 0).reshape(-1, 1), zeta_1_enc, zeta_2_enc).contiguous()
+        return pai.add_batch(pai.add_batch(zeta, d_factor), corr)

@@ -291,6 +291,10 @@ class Paillier(_Scheme):
         """[[m]] = 1 + m N mod N^2 without randomness, for plaintext words [count][<= 2*nw]."""
         return self.engine.paillier_encrypt_raw(self.mod_n2, self.public_key.n, m_words)
 
+    def encrypt_raw_neg_batch(self, m_words: torch.Tensor) -> torch.Tensor:
+        """[[-m]] = 1 - m N mod N^2 = ([[m]])^-1, with no modular inversion."""
+        return self.engine.paillier_encrypt_raw_neg(self.mod_n2, self.public_key.n, m_words)
+
     def randomizer_batch(self, rho: torch.Tensor) -> torch.Tensor:
         """rho^N mod N^2 for rho words [count][nw(N)]."""
         return self.randomize_batch(None, rho)

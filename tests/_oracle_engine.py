@@ -97,6 +97,9 @@ class OracleEngine:
     def paillier_encrypt_raw(self, mod_n2, n, m, out=None):
         return self.upload([(1 + (v % n) * n) % mod_n2.n for v in self._ints(m)], mod_n2.nwords)
 
+    def paillier_encrypt_raw_neg(self, mod_n2, n, m, out=None):
+        return self.upload([(1 - (v % n) * n) % mod_n2.n for v in self._ints(m)], mod_n2.nwords)
+
     def paillier_l_mul(self, mod, k, x, out=None):
         return self.upload([((v % (mod.n * mod.n)) - 1) // mod.n * k % mod.n for v in self._ints(x)], mod.nwords)
 

@@ -408,3 +408,29 @@ def test_worst_case_limbs(engine, bits):
     assert engine.download(engine.modexp_shared(mod, engine.upload(wide, 2 * mod.nwords), 3)) == [pow(w, 3, n) for w in wide]
     ev = [(1 << 67) - 1, (1 << 66) + 12345, 7, 1, 0, (1 << 35) - 1, 3, 2]
     assert engine.download(engine.modexp_var(mod, t, engine.upload(ev, 3), 67)) == [pow(v, x, n) for v, x in zip(vals, ev)]
+
+
+def test_steps_6_7_fused_equals_separate(engine, keys):
+    """Initiator.step_6_7_batch (one inversion) gives the same residues as step_6_batch followed by step_7_batch (two), and
+    sc_paillier_encrypt_raw_neg equals the modular inverse of sc_paillier_encrypt_raw (incl. m = 0)."""
+    from protocols.secure_comparison_amd import Initiator, Paillier
+
+    sk = oracle_paillier(keys, 2048)
+    pai = Paillier(sk.n, engine=engine)
+    rng = random.Random(12)
+    B, l, nw = 50, 32, pai.mod_n.nwords
+    ms = [0, 1, sk.n - 1] + [rng.randrange(sk.n) for _ in range(B - 3)]
+    neg = pai.encrypt_raw_neg_batch(engine.upload(ms, nw))
+    assert engine.download(neg) == [sk.neg(sk.enc_raw(m)) for m in ms]
+    rs = [rng.randrange(sk.n) for _ in range(B)]
+    rs[0], rs[1] = 5, sk.n - 5
+    _, plain = Initiator.step_1_batch(engine.upload([sk.enc_raw(1)] * B, 2 * nw), engine.upload([sk.enc_raw(2)] * B, 2 * nw), l, pai,
+                                      engine.upload(rs, nw))
+    rnd = lambda m: sk.randomize(sk.enc_raw(m), 1 + rng.randrange(sk.n - 1))  # noqa: E731
+    da = [rng.randrange(2) for _ in range(B)]
+    db, z1, z2 = [rnd(rng.randrange(2)) for _ in range(B)], [rnd(rng.randrange(1 << 40)) for _ in range(B)], [rnd(rng.randrange(1 << 40)) for _ in range(B)]
+    tda, tdb, tz1, tz2 = engine.upload_u64(da), engine.upload(db, 2 * nw), engine.upload(z1, 2 * nw), engine.upload(z2, 2 * nw)
+    sep = Initiator.step_7_batch(tz1, tz2, plain, l, Initiator.step_6_batch(tda, tdb, pai), pai)
+    fused = Initiator.step_6_7_batch(tda, tdb, tz1, tz2, plain, l, pai)
+    expect = [o.step_7(a, b, r, l, o.step_6(d, c, sk), sk) for a, b, r, d, c in zip(z1, z2, rs, da, db)]
+    assert engine.download(sep) == expect and engine.download(fused) == expect
