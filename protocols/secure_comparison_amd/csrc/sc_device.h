@@ -29,11 +29,11 @@ __device__ __forceinline__ uint32_t bcast0(uint32_t v) {  // value of the group'
   if constexpr (G == 1) {
     return v;
   } else if constexpr (G == 2) {
-    return __builtin_amdgcn_update_dpp(0u, v, 0xA0, 0xf, 0xf, false);  // quad_perm:[0,0,2,2]
+    return __builtin_amdgcn_mov_dpp(v, 0xA0, 0xf, 0xf, false);  // quad_perm:[0,0,2,2]
   } else if constexpr (G == 4) {
-    return __builtin_amdgcn_update_dpp(0u, v, 0x00, 0xf, 0xf, false);  // quad_perm:[0,0,0,0]
+    return __builtin_amdgcn_mov_dpp(v, 0x00, 0xf, 0xf, false);  // quad_perm:[0,0,0,0]
   } else if constexpr (G == 16) {
-    return __builtin_amdgcn_update_dpp(0u, v, 0x150, 0xf, 0xf, false);  // row_newbcast:0
+    return __builtin_amdgcn_mov_dpp(v, 0x150, 0xf, 0xf, false);  // row_newbcast:0
   } else {
     static_assert(G == 8, "unsupported group size");
     uint32_t lo = __builtin_amdgcn_update_dpp(v, v, 0x150, 0xf, 0x3, false);   // lanes 0-7  <- lane 0 (others keep v for now)
@@ -42,11 +42,11 @@ __device__ __forceinline__ uint32_t bcast0(uint32_t v) {  // value of the group'
 }
 // lane i receives lane i+1 of its 16-lane row (row end: 0)
 __device__ __forceinline__ uint32_t row_from_above(uint32_t v) {
-  return __builtin_amdgcn_update_dpp(0u, v, 0x101, 0xf, 0xf, true);  // row_shl:1
+  return __builtin_amdgcn_mov_dpp(v, 0x101, 0xf, 0xf, true);  // row_shl:1 (bound_ctrl: out-of-row source reads 0)
 }
 // lane i receives lane i-1 of its 16-lane row (row start: 0)
 __device__ __forceinline__ uint32_t row_from_below(uint32_t v) {
-  return __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, true);  // row_shr:1
+  return __builtin_amdgcn_mov_dpp(v, 0x111, 0xf, 0xf, true);  // row_shr:1
 }
 
 // ---------------------------------------------------------------------------------------------
