@@ -139,7 +139,7 @@ struct Grp {
         // The low limb moves to the lane below and becomes its new top column.  No group-boundary mask is needed:
         // the bottom lane of the group above contributes exactly 0 (its column 0 was just made divisible by 2^29),
         // and the DPP row end reads 0 (bound_ctrl).
-        T[l] = (uint64_t)from_above_raw((uint32_t)t0 & LMASK);
+        T[l] = (uint64_t)(from_above_raw((uint32_t)t0) & LMASK);  // mask after the move: folds into v_and_b32_dpp
       }
     }
     // one local carry pass + hand the lane carry to the next lane (result "almost normalised")
