@@ -38,7 +38,7 @@ def literal_macs_per_comparison(l: int, pbits: int, dbits: int, rbits: int) -> f
         return (kbits + -(-kbits // 5) + 30) * mm(modbits)
     e_p = e_var(pbits, 2 * pbits)
     e_h = -(-rbits // 8) * mm(dbits)
-    e_rho = e_var(l + 3, dbits) if False else (l + 3 + -(-(l + 3) // 5) + 10) * mm(dbits)
+    e_rho = (l + 3 + -(-(l + 3) // 5) + 10) * mm(dbits)   # (l+3)-bit blinding exponent, about 52 modmuls at l = 32
     e_0 = e_var(160, dbits // 2)
     m_n = mm(dbits)
     return 5 * e_p + 2 * (l + 1) * e_h + (l + 1) * e_rho + (l + 1) * e_0 + l * (l - 1) / 2 * m_n + 9 * l * m_n + 3 * 2.5 * l * m_n
