@@ -434,3 +434,50 @@ def test_steps_6_7_fused_equals_separate(engine, keys):
     fused = Initiator.step_6_7_batch(tda, tdb, tz1, tz2, plain, l, pai)
     expect = [o.step_7(a, b, r, l, o.step_6(d, c, sk), sk) for a, b, r, d, c in zip(z1, z2, rs, da, db)]
     assert engine.download(sep) == expect and engine.download(fused) == expect
+
+
+def test_c_abi_without_torch_buffers():
+    """The boundary is a plain C ABI: drive it with ctypes only (sc_malloc / sc_memcpy_*), no torch tensor in sight."""
+    import ctypes as C
+
+    import numpy as np
+
+    from protocols.secure_comparison_amd import _lib
+    from protocols.secure_comparison_amd.limbs import ints_to_words, words_to_ints
+
+    lib = _lib.load()
+    ctx = C.c_void_p()
+    assert lib.sc_ctx_create(0, C.byref(ctx)) == 0
+    try:
+        rng = random.Random(77)
+        n = rng.getrandbits(2048) | (1 << 2047) | 1
+        nw, count = 64, 33
+        a, b = [rng.randrange(n) for _ in range(count)], [rng.randrange(n) for _ in range(count)]
+        mod, exp = C.c_int(), C.c_int()
+        n_words = ints_to_words([n], nw)
+        assert lib.sc_mod_create(ctx, n_words.ctypes.data_as(C.c_void_p), nw, C.byref(mod)) == 0
+        assert lib.sc_mod_words(ctx, mod.value) == nw
+        e = 0x10001
+        e_words = ints_to_words([e], 1)
+        assert lib.sc_exp_create(ctx, e_words.ctypes.data_as(C.c_void_p), 1, C.byref(exp)) == 0
+        bufs = []
+        for _ in range(3):
+            p = C.c_void_p()
+            assert lib.sc_malloc(ctx, count * nw * 4, C.byref(p)) == 0
+            bufs.append(p)
+        for p, vals in zip(bufs, (a, b)):
+            host = ints_to_words(vals, nw)
+            assert lib.sc_memcpy_h2d(ctx, p, host.ctypes.data_as(C.c_void_p), host.nbytes) == 0
+        out = np.zeros((count, nw), dtype=np.uint32)
+        assert lib.sc_modmul(ctx, mod.value, bufs[0], nw, bufs[1], nw, bufs[2], count) == 0
+        assert lib.sc_memcpy_d2h(ctx, out.ctypes.data_as(C.c_void_p), bufs[2], out.nbytes) == 0
+        assert words_to_ints(out) == [x * y % n for x, y in zip(a, b)]
+        assert lib.sc_modexp_shared(ctx, mod.value, exp.value, bufs[0], nw, bufs[1], bufs[2], count) == 0
+        assert lib.sc_memcpy_d2h(ctx, out.ctypes.data_as(C.c_void_p), bufs[2], out.nbytes) == 0
+        assert words_to_ints(out) == [pow(x, e, n) * y % n for x, y in zip(a, b)]
+        assert lib.sc_modmul(ctx, mod.value, None, nw, bufs[1], nw, bufs[2], count) == -1      # SC_ERR_ARG, message available
+        assert b"sc_modmul" in lib.sc_last_error(ctx)
+        for p in bufs:
+            assert lib.sc_free(ctx, p) == 0
+    finally:
+        lib.sc_ctx_destroy(ctx)
