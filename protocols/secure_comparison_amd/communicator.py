@@ -1,11 +1,46 @@
-"""Transport contract between the two players (reference: communicator.py:8-11).  Out of scope as a product
-component -- any object with these two coroutines works (the tests use an in-memory dictionary)."""
+"""Message transport between the two players.
+
+Any object with awaitable ``send(party_id, message, msg_id)`` and ``recv(party_id, msg_id)`` works (structural typing,
+as in the reference's communicator module); the inter-party HTTP transport itself is out of scope here.
+``InMemoryCommunicator`` is a minimal single-process transport for demos and tests: both players share one mailbox
+and messages are keyed by their ``msg_id`` (the session-numbered step names keep concurrent runs apart).
+"""
 from __future__ import annotations
 
-from typing import Any, Protocol
+import asyncio
+from typing import Any, Protocol, runtime_checkable
 
 
+@runtime_checkable
 class Communicator(Protocol):
-    async def send(self, party_id: str, message: Any, msg_id: str | None = None) -> None: ...
+    """Structural type of a transport usable by Initiator and KeyHolder."""
 
-    async def recv(self, party_id: str, msg_id: str | None = None) -> Any: ...
+    async def send(self, party_id: str, message: Any, msg_id: str) -> None:
+        """Deliver `message` to `party_id` under the label `msg_id`."""
+
+    async def recv(self, party_id: str, msg_id: str) -> Any:
+        """Wait for the message labelled `msg_id` from `party_id`."""
+
+
+class InMemoryCommunicator:
+    """Shared-mailbox transport for two players living in one event loop."""
+
+    def __init__(self, mailbox: dict[str, Any] | None = None, max_polls: int = 1_000_000) -> None:
+        self.mailbox: dict[str, Any] = {} if mailbox is None else mailbox
+        self.max_polls = max_polls
+
+    def peer(self) -> "InMemoryCommunicator":
+        """A second endpoint on the same mailbox (hand it to the other player)."""
+        return InMemoryCommunicator(self.mailbox, self.max_polls)
+
+    async def send(self, party_id: str, message: Any, msg_id: str) -> None:
+        if msg_id in self.mailbox:
+            raise RuntimeError(f"message id {msg_id!r} is already pending")
+        self.mailbox[msg_id] = message
+
+    async def recv(self, party_id: str, msg_id: str) -> Any:
+        for _ in range(self.max_polls):
+            if msg_id in self.mailbox:
+                return self.mailbox.pop(msg_id)
+            await asyncio.sleep(0)
+        raise TimeoutError(f"no message {msg_id!r} from {party_id!r}")
