@@ -108,13 +108,13 @@ def synth_inputs(eng, l, alice_p, bob_p, bob_d, B, rbits, seed):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=65536, help="comparisons per GPU per step")
     ap.add_argument("--l", type=int, default=32)
     ap.add_argument("--pbits", type=int, default=2048)
     ap.add_argument("--rbits", type=int, default=400)
-    ap.add_argument("--fb-window", type=int, default=13)
+    ap.add_argument("--fb-window", type=int, default=16, help="window of the fixed-base table for h (2^w rows of 288 B per window, HBM-resident)")
     ap.add_argument("--no-crt", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0)
