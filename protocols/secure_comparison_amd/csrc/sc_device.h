@@ -36,6 +36,8 @@ __device__ __forceinline__ uint32_t bcast0(uint32_t v) {  // value of the group'
     return __builtin_amdgcn_mov_dpp(v, 0x150, 0xf, 0xf, false);  // row_newbcast:0
   } else {
     static_assert(G == 8, "unsupported group size");
+    // two DPP moves; a single ds_swizzle (LDS crossbar, no VALU slot) was measured 4 % slower: its latency sits on
+    // the quotient-digit critical path
     uint32_t lo = __builtin_amdgcn_update_dpp(v, v, 0x150, 0xf, 0x3, false);   // lanes 0-7  <- lane 0 (others keep v for now)
     return __builtin_amdgcn_update_dpp(lo, v, 0x158, 0xf, 0xc, false);         // lanes 8-15 <- lane 8
   }
