@@ -36,7 +36,7 @@ class InMemoryCommunicator:
     async def send(self, party_id: str, message: Any, msg_id: str) -> None:
         if msg_id in self.mailbox:
             raise RuntimeError(f"message id {msg_id!r} is already pending")
-        self.mailbox[msg_id] = message
+        self.mailbox[msg_id] = _as_on_wire(message)
 
     async def recv(self, party_id: str, msg_id: str) -> Any:
         for _ in range(self.max_polls):
@@ -44,3 +44,15 @@ class InMemoryCommunicator:
                 return self.mailbox.pop(msg_id)
             await asyncio.sleep(0)
         raise TimeoutError(f"no message {msg_id!r} from {party_id!r}")
+
+
+def _as_on_wire(message: Any) -> Any:
+    """Mimic what a serializing transport does to ciphertext objects (the reference's transports randomize a non-fresh
+    ciphertext, with a warning, when it is serialized): nested tuples / lists are walked, other payloads pass through."""
+    if hasattr(message, "for_wire"):
+        return message.for_wire()
+    if isinstance(message, tuple):
+        return tuple(_as_on_wire(m) for m in message)
+    if isinstance(message, list):
+        return [_as_on_wire(m) for m in message]
+    return message

@@ -24,6 +24,13 @@ from . import keygen
 WARN_INEFFICIENT_RANDOMIZATION = (
     "Randomizing a fresh ciphertext wastes randomness: the ciphertext was already randomized and unused."
 )
+WARN_INEFFICIENT_HOM_OPERATION = (
+    "A fresh ciphertext was used as input to a homomorphic operation and is no longer fresh afterwards: its randomness "
+    "is wasted if the result is randomized again.  Randomize ciphertexts as late as possible (just before sending)."
+)
+WARN_UNFRESH_SERIALIZATION = (
+    "Serializing a ciphertext that is not fresh: it is randomized first.  Call ciphertext.randomize() before sending."
+)
 WARN_OUT_OF_RANDOMNESS = (
     "No pre-generated randomness available; generating randomness on the fly "
     "(boot_randomness_generation can pre-generate it)."
@@ -69,10 +76,29 @@ class _Ciphertext:
 
     @property
     def value(self) -> int:
+        """The ciphertext integer; reading it this way ends the ciphertext's freshness (it may have been observed)."""
+        self._fresh = False
         return self._raw_value
 
     def peek_value(self) -> int:
+        """The ciphertext integer without touching the freshness flag."""
         return self._raw_value
+
+    def get_value(self) -> int:
+        """Value for use in a homomorphic operation: warns when a fresh ciphertext is consumed that way."""
+        if self._fresh:
+            warnings.warn(WARN_INEFFICIENT_HOM_OPERATION, UserWarning)
+        self._fresh = False
+        return self._raw_value
+
+    def for_wire(self):
+        """What a transport should put on the wire: a fresh ciphertext (randomizing first, with a warning, if this one is
+        not fresh); the sender's copy stops being fresh because it has been disclosed."""
+        if not self._fresh:
+            warnings.warn(WARN_UNFRESH_SERIALIZATION, UserWarning)
+            self.randomize()
+        self._fresh = False
+        return type(self)(self._raw_value, self.scheme)
 
     @property
     def fresh(self) -> bool:
@@ -94,11 +120,11 @@ class _Ciphertext:
         if isinstance(other, _Ciphertext):
             if other.scheme != self.scheme:
                 raise ValueError("ciphertexts belong to different schemes")
-            return other._raw_value
+            return other.get_value()
         return self.scheme._unsafe_encrypt_raw_value(self.scheme._encode(other))
 
     def __add__(self, other: Any):
-        return type(self)(self.scheme._mul_values(self._raw_value, self._coerce(other)), self.scheme)
+        return type(self)(self.scheme._mul_values(self.get_value(), self._coerce(other)), self.scheme)
 
     __radd__ = __add__
 
@@ -106,7 +132,7 @@ class _Ciphertext:
         return self.__add__(other)
 
     def __neg__(self):
-        return type(self)(self.scheme._inv_value(self._raw_value), self.scheme)
+        return type(self)(self.scheme._inv_value(self.get_value()), self.scheme)
 
     def __sub__(self, other: Any):
         if isinstance(other, _Ciphertext):
@@ -119,7 +145,7 @@ class _Ciphertext:
     def __mul__(self, scalar: int):
         if not isinstance(scalar, int):
             raise TypeError("ciphertexts can only be multiplied by integers")
-        return type(self)(self.scheme._pow_value(self._raw_value, scalar), self.scheme)
+        return type(self)(self.scheme._pow_value(self.get_value(), scalar), self.scheme)
 
     __rmul__ = __mul__
 

@@ -250,3 +250,30 @@ def test_wire_and_randomness_helpers():
     assert torch.equal(a, t) and torch.equal(b, perms) and c.dtype == torch.uint8
     with pytest.raises(ValueError):
         wire.unpack_tensor(b"nope" + bytes(16))
+
+
+def test_freshness_discipline(world):
+    """The fresh-flag rules the reference's strict fixtures rely on (test/conftest.py:26-36, README.md:152-154)."""
+    osk, od, eng, pai, dgk = world
+    pai.shut_down()
+    pai.boot_randomness_generation(3)
+    a = pai.unsafe_encrypt(4)
+    assert not a.fresh
+    a.randomize()
+    assert a.fresh
+    with pytest.warns(UserWarning, match=".*ciphertext"):
+        b = a + 1                      # a fresh ciphertext consumed by a homomorphic operation
+    assert not a.fresh and not b.fresh and pai.decrypt(b) == 5
+    comm = DictionaryCommunicator({})
+    with pytest.warns(UserWarning, match=".*ciphertext"):
+        asyncio.run(comm.send("bob", b, msg_id="m1"))   # non-fresh on the wire: randomized first, with a warning
+    got = asyncio.run(comm.recv("alice", msg_id="m1"))
+    assert not got.fresh and got.peek_value() != osk.enc_raw(5) and pai.decrypt(got) == 5
+    c = pai.unsafe_encrypt(9)
+    c.randomize()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        asyncio.run(comm.send("bob", c, msg_id="m2"))    # fresh ciphertext: no warning
+    assert not c.fresh                 # disclosed
+    assert c.peek_value() == asyncio.run(comm.recv("alice", msg_id="m2")).peek_value()
+    pai.shut_down()
