@@ -39,8 +39,8 @@ struct MW {
     }
   }
   static __device__ __forceinline__ void shr1(uint32_t (&x)[WPL]) {
-    uint32_t up = __shfl_down(x[0], 1);
-    if ((threadIdx.x & 63) == 63) up = 0;
+    // wave_shl:1 -- lane i reads lane i+1 across the whole wave (gfx9 DPP), lane 63 reads 0
+    const uint32_t up = __builtin_amdgcn_update_dpp(0u, x[0], 0x130, 0xf, 0xf, true);
 #pragma unroll
     for (int k = 0; k < WPL; k++) {
       const uint32_t nxt = (k + 1 < WPL) ? x[k + 1] : up;
@@ -48,8 +48,8 @@ struct MW {
     }
   }
   static __device__ __forceinline__ void shl1(uint32_t (&x)[WPL]) {
-    uint32_t dn = __shfl_up(x[WPL - 1], 1);
-    if ((threadIdx.x & 63) == 0) dn = 0;
+    // wave_shr:1 -- lane i reads lane i-1, lane 0 reads 0
+    const uint32_t dn = __builtin_amdgcn_update_dpp(0u, x[WPL - 1], 0x138, 0xf, 0xf, true);
 #pragma unroll
     for (int k = WPL - 1; k >= 0; k--) {
       const uint32_t prv = (k > 0) ? x[k - 1] : dn;
@@ -76,7 +76,7 @@ struct MW {
     for (int k = 0; k < WPL; k++) o |= (k == 0 && (threadIdx.x & 63) == 0) ? (x[k] ^ 1u) : x[k];
     return __ballot(o != 0) == 0;
   }
-  static __device__ __forceinline__ bool odd(const uint32_t (&x)[WPL]) { return __shfl((int)(x[0] & 1u), 0) != 0; }
+  static __device__ __forceinline__ bool odd(const uint32_t (&x)[WPL]) { return (__builtin_amdgcn_readfirstlane(x[0]) & 1u) != 0; }
 };
 
 template <int WPL>
