@@ -481,3 +481,26 @@ def test_c_abi_without_torch_buffers():
             assert lib.sc_free(ctx, p) == 0
     finally:
         lib.sc_ctx_destroy(ctx)
+
+
+@pytest.mark.parametrize("l", [1, 2, 5, 33])
+def test_small_and_odd_bit_lengths(engine, keys, l):
+    """Edge bit lengths (l = 1: a single bit, no suffix product; l = 33: bit index crosses a 32-bit word) with a DGK key
+    generated for the matching u = next_prime(2^(l+2)), every comparison in range enumerated for tiny l."""
+    from protocols.secure_comparison_amd.batch import secure_comparison_batch
+
+    sk = oracle_paillier(keys, 1024)
+    rng = random.Random(400 + l)
+    dgk = o.DGKKey.generate(40, 512, o.next_prime(1 << (l + 2)), rng)
+    alice_p, alice_d, bob_p, bob_d = _schemes(engine, sk, dgk, 100)
+    pairs = [(x, y) for x in range(1 << l) for y in range(1 << l)] if l <= 2 else \
+        [(rng.randrange(1 << l), rng.randrange(1 << l)) for _ in range(12)] + [(5, 5), ((1 << l) - 1, (1 << l) - 1), (0, (1 << l) - 1)]
+    drs = [o.draw(rng, l, sk, dgk, 100) for _ in pairs]
+    x_enc = [sk.enc_raw(x) for x, _ in pairs]
+    y_enc = [sk.enc_raw(y) for _, y in pairs]
+    expect = [o.compare(a, b, l, sk, dgk, d, True) for a, b, d in zip(x_enc, y_enc, drs)]
+    nw = bob_p.mod_n.nwords
+    draws = _draw_tensors(engine, drs, l, nw, (dgk.u.bit_length() + 31) // 32, 4, engine.device)
+    got = engine.download(secure_comparison_batch(engine.upload(x_enc, 2 * nw), engine.upload(y_enc, 2 * nw), l, alice_p, alice_d,
+                                                  bob_p, bob_d, draws))
+    assert got == expect and [sk.dec_raw(c) for c in got] == [int(x <= y) for x, y in pairs]
