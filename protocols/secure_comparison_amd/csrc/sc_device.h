@@ -18,8 +18,7 @@
 
 namespace sc {
 
-constexpr int W = 29;
-constexpr uint32_t LMASK = (1u << W) - 1;
+constexpr int W_DEFAULT = 29;  // limb width of the standard configurations (a 28-bit family exists for L = 37)
 
 // ---------------------------------------------------------------------------------------------
 // cross-lane helpers (DPP; a group never straddles a 16-lane DPP row because G divides 16)
@@ -54,9 +53,12 @@ __device__ __forceinline__ uint32_t row_from_below(uint32_t v) {
 // ---------------------------------------------------------------------------------------------
 // Per-thread view of the group it belongs to.
 // ---------------------------------------------------------------------------------------------
-template <int G_, int L_>
+template <int G_, int L_, int W_ = W_DEFAULT>
 struct Grp {
   static constexpr int G = G_, L = L_, S = G_ * L_, NG = 64 / G_;
+  static constexpr int W = W_;                          // bits per limb: 2L products of 2W bits must fit 64 bits
+  static constexpr uint32_t LMASK = (1u << W_) - 1;
+  static_assert(2 * W_ + 6 <= 64 && (2 * L_ + 2) <= (1 << (64 - 2 * W_ - 1)) * 2, "column accumulators would overflow");
   static constexpr int SP = S + 3;                      // padded limb-array stride in LDS (odd)
   static constexpr int WP = (W * S + 31) / 32 + 2;      // 32-bit-word scratch stride in LDS
   int lane, g, j;                                       // lane in wave, group in wave, lane in group

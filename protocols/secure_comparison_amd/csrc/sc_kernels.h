@@ -12,9 +12,9 @@ namespace sc {
 // The micro-op interpreter.  One 64-lane workgroup (= one wave) processes 64/G items per pass of
 // the program and grid-strides over the batch.
 // ---------------------------------------------------------------------------------------------
-template <int G, int L>
+template <int G, int L, int WB>
 __global__ void __launch_bounds__(64, ((L > 18 || G == 16) ? 1 : SC_VM_WAVES)) k_vm(const VmArgs args) {
-  using GT = Grp<G, L>;
+  using GT = Grp<G, L, WB>;
   constexpr int S = GT::S, NG = GT::NG, SP = GT::SP, WP = GT::WP;
   __shared__ uint32_t s_a[NG * SP];            // per-group staging area for the LDS-side operand
   __shared__ uint32_t s_a2[NG * SP];           // the same operand doubled (squarings only)

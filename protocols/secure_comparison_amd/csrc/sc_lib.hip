@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -61,22 +62,26 @@ Big big_shl_mod(const Big& x, const Big& n, int k) {
   v.resize(n.size());
   return v;
 }
-std::vector<uint32_t> to_limbs(const Big& x, int S) {
+std::vector<uint32_t> to_limbs(const Big& x, int S, int W) {
   std::vector<uint32_t> out(S, 0);
+  const uint32_t mask = (1u << W) - 1;
   for (int i = 0; i < S; i++) {
     int bit = W * i, w0 = bit >> 5, sh = bit & 31;
     uint64_t v = (w0 < (int)x.size()) ? x[w0] : 0;
     if (w0 + 1 < (int)x.size()) v |= (uint64_t)x[w0 + 1] << 32;
-    out[i] = (uint32_t)(v >> sh) & LMASK;
+    out[i] = (uint32_t)(v >> sh) & mask;
   }
   return out;
 }
 
-struct Config { int G, L; };
-const Config kConfigs[] = {{1, 18}, {2, 18}, {2, 27}, {4, 18}, {4, 27}, {8, 18}, {8, 27}, {16, 18}};
+struct Config { int G, L, W; };
+// ordered by capacity W*G*L; sc_mod_create takes the first one that fits.  A 28-bit-limb L = 37 family ((2,37), (4,37)) was
+// built and measured in round 1: it needs > 256 registers (one wave per SIMD plus AGPR copies) and came out 2-3 % slower
+// than (4,18) / (8,18), so it is not compiled in; the limb width stays a template parameter for such experiments.
+const Config kConfigs[] = {{1, 18, 29}, {2, 18, 29}, {2, 27, 29}, {4, 18, 29}, {4, 27, 29}, {8, 18, 29}, {8, 27, 29}, {16, 18, 29}};
 
 struct Mod {
-  int G = 0, L = 0, S = 0, nwords = 0, nbits = 0;
+  int G = 0, L = 0, W = 29, S = 0, nwords = 0, nbits = 0;
   Big n;
   uint32_t n0inv = 0;
   uint32_t* d_ctx = nullptr;  // n | R^2 | R  limb form
@@ -251,13 +256,13 @@ int finalize_prog(sc_ctx* ctx, const Mod& m, Builder& b, Prog* out) {
   return SC_OK;
 }
 
-template <int G, int L>
+template <int G, int L, int WB>
 int launch_vm_cfg(sc_ctx* ctx, const VmArgs& a, int cfg_index) {
   auto it = ctx->occ_cache.find(cfg_index);
   int occ;
   if (it == ctx->occ_cache.end()) {
     int nb = 0;
-    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_vm<G, L>, 64, 0));
+    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_vm<G, L, WB>, 64, 0));
     occ = std::max(1, std::min(nb, 16));
     ctx->occ_cache[cfg_index] = occ;
   } else {
@@ -272,7 +277,7 @@ int launch_vm_cfg(sc_ctx* ctx, const VmArgs& a, int cfg_index) {
   if (rc) return rc;
   VmArgs args = a;
   args.scratch = ctx->scratch;
-  hipLaunchKernelGGL((k_vm<G, L>), dim3(grid), dim3(64), 0, ctx->stream, args);
+  hipLaunchKernelGGL((k_vm<G, L, WB>), dim3(grid), dim3(64), 0, ctx->stream, args);
   HIPCHK(ctx, hipGetLastError());
   return SC_OK;
 }
@@ -297,8 +302,9 @@ int run_vm(sc_ctx* ctx, int mod, const Prog& p, const VmExt* exts, int next, uin
                                         p.sqrs_per_item * (double)m.G * m.L * (m.L + 1) / 2.0);
   int rc = SC_ERR_UNSUPPORTED;
   int ci = 0;
-#define SC_CASE(GG, LL) if (m.G == GG && m.L == LL) rc = launch_vm_cfg<GG, LL>(ctx, a, ci); ci++;
-  SC_CASE(1, 18) SC_CASE(2, 18) SC_CASE(2, 27) SC_CASE(4, 18) SC_CASE(4, 27) SC_CASE(8, 18) SC_CASE(8, 27) SC_CASE(16, 18)
+#define SC_CASE(GG, LL, WW) if (m.G == GG && m.L == LL && m.W == WW) rc = launch_vm_cfg<GG, LL, WW>(ctx, a, ci); ci++;
+  SC_CASE(1, 18, 29) SC_CASE(2, 18, 29) SC_CASE(2, 27, 29) SC_CASE(4, 18, 29) SC_CASE(4, 27, 29) SC_CASE(8, 18, 29) SC_CASE(8, 27, 29)
+  SC_CASE(16, 18, 29)
 #undef SC_CASE
   if (rc == SC_ERR_UNSUPPORTED) return fail(ctx, rc, "no kernel configuration for G=%d L=%d", m.G, m.L);
   return rc;
@@ -421,16 +427,21 @@ int sc_mod_create(sc_ctx* ctx, const uint32_t* n_hptr, int nwords, int* out_mod)
   m.nwords = nwords;
   m.nbits = big_bits(m.n);
   if (m.nbits < 2 || !(m.n[0] & 1)) return fail(ctx, SC_ERR_ARG, "sc_mod_create: modulus must be odd and > 1");
-  for (const Config& c : kConfigs)
-    if (W * c.G * c.L >= m.nbits + 8 && W * c.G * c.L >= 32 * nwords) { m.G = c.G; m.L = c.L; break; }
-  if (!m.G) {
-    for (const Config& c : kConfigs) if (W * c.G * c.L >= m.nbits + 8) { m.G = c.G; m.L = c.L; break; }
-  }
+  auto fits = [&](const Config& c, bool need_words) {
+    const int cap = c.W * c.G * c.L;
+    return cap >= m.nbits + 8 && (!need_words || cap >= 32 * nwords);
+  };
+  for (int pass = 0; pass < 2 && !m.G; pass++)
+    for (const Config& c : kConfigs) {
+      if (fits(c, pass == 0)) { m.G = c.G; m.L = c.L; m.W = c.W; break; }
+    }
   if (!m.G) return fail(ctx, SC_ERR_UNSUPPORTED, "sc_mod_create: %d-bit modulus exceeds the largest configuration", m.nbits);
   m.S = m.G * m.L;
-  // the residue arrays must be representable below R = 2^(29 S)
+  const int W = m.W;
+  const uint32_t LMASK = (1u << W) - 1;
+  // the residue arrays must be representable below R = 2^(W S)
   if (32 * nwords > W * m.S + 31) return fail(ctx, SC_ERR_ARG, "sc_mod_create: nwords=%d too wide for a %d-bit modulus", nwords, m.nbits);
-  // n0inv = -n^-1 mod 2^29 (Newton)
+  // n0inv = -n^-1 mod 2^W (Newton)
   uint32_t n0 = m.n[0], inv = 1;
   for (int i = 0; i < 6; i++) inv *= 2 - n0 * inv;
   m.n0inv = (0u - inv) & LMASK;
@@ -438,7 +449,7 @@ int sc_mod_create(sc_ctx* ctx, const uint32_t* n_hptr, int nwords, int* out_mod)
   Big r1 = big_shl_mod(one, m.n, W * m.S);
   Big r2 = big_shl_mod(r1, m.n, W * m.S);
   std::vector<uint32_t> ctxv;
-  auto app = [&](const Big& x) { auto l = to_limbs(x, m.S); ctxv.insert(ctxv.end(), l.begin(), l.end()); };
+  auto app = [&](const Big& x) { auto l = to_limbs(x, m.S, W); ctxv.insert(ctxv.end(), l.begin(), l.end()); };
   app(m.n); app(r2); app(r1);
   int rc = upload(ctx, ctxv.data(), ctxv.size() * 4, (void**)&m.d_ctx);
   if (rc) return rc;
@@ -463,8 +474,8 @@ int sc_const_create(sc_ctx* ctx, int mod, const uint32_t* v_hptr, int nwords, in
   Big v(v_hptr, v_hptr + nwords);
   v.resize(std::max(nwords, m.nwords), 0);
   Big nn = m.n; nn.resize(v.size(), 0);
-  Big vm = big_shl_mod(v, nn, W * m.S);  // Montgomery form
-  auto l = to_limbs(vm, m.S);
+  Big vm = big_shl_mod(v, nn, m.W * m.S);  // Montgomery form
+  auto l = to_limbs(vm, m.S, m.W);
   Const c; c.mod = mod;
   int rc = upload(ctx, l.data(), l.size() * 4, (void**)&c.d_limbs);
   if (rc) return rc;
@@ -707,7 +718,7 @@ int sc_paillier_l_mul(sc_ctx* ctx, int mod, int cst_k, const uint32_t* x, int x_
   auto it = ctx->progs.find(key);
   if (it == ctx->progs.end()) {
     Builder bd; int c = bd.use_const(cst_k);
-    const int lw = std::min(x_words, (W * m.S + 31) / 32);   // only x mod R matters for the exact quotient
+    const int lw = std::min(x_words, (m.W * m.S + 31) / 32);   // only x mod R matters for the exact quotient
     bd.loadw(0, 0, 0, lw);
     bd.emit(OP_SUB1);                 // y = (x - 1) mod R, exact limbs
     bd.emit(OP_QUOT); bd.redcs++;     // y / n  (< n because x < n^2)
