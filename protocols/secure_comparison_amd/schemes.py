@@ -15,7 +15,7 @@ from __future__ import annotations
 
 import secrets
 import warnings
-from typing import Any, Iterable, Sequence
+from typing import Any
 
 import torch
 

@@ -12,7 +12,7 @@ from _comm import DictionaryCommunicator
 from _oracle_engine import OracleEngine
 from conftest import oracle_dgk, oracle_paillier
 from oracle import sc_oracle as o
-from protocols.secure_comparison_amd import DGK, Initiator, KeyHolder, Paillier, PaillierCiphertext
+from protocols.secure_comparison_amd import DGK, Initiator, KeyHolder, Paillier
 from protocols.secure_comparison_amd.batch import BatchDraws, BatchTrace, secure_comparison_batch
 
 L = 16
