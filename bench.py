@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from protocols.secure_comparison_amd import DGK, Paillier  # noqa: E402
-from protocols.secure_comparison_amd.batch import BatchDraws, secure_comparison_batch  # noqa: E402
+from protocols.secure_comparison_amd.batch import BatchDraws, boot_pools, secure_comparison_batch  # noqa: E402
 from protocols.secure_comparison_amd.schemes import default_engine  # noqa: E402
 
 KEYS = os.path.join(ROOT, "tests", "golden", "keys.json")
@@ -246,6 +246,19 @@ def main() -> None:
             "roofline_hbm": {"bound": "hbm", "achieved": abytes * value / world / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": abytes * value / world / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_comparison": abytes},
         }
+        # ---- online phase only (reported, never `value`): randomizers pre-generated into device pools (untimed), as the
+        # reference pre-generates them in background workers (boot_randomness_generation, SC/initiator.py:205-210)
+        gen = torch.Generator(device=eng.device)
+        gen.manual_seed(1234)
+        boot_pools(B, l, alice_p, alice_d, bob_p, bob_d, source="torch", generator=gen)
+        torch.cuda.synchronize()
+        to = time.perf_counter()
+        ro = secure_comparison_batch(x_enc, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws, randomize="pool")
+        torch.cuda.synchronize()
+        online_s = time.perf_counter() - to
+        dec_o = bob_p.decrypt_raw_batch(ro)
+        out["online_phase_only"] = {"value": B / online_s, "unit": "comparisons/s", "correct": bool((dec_o[:, 0] == (x <= y).to(torch.int32)).all().item()),
+                                    "note": "all 4 + 2(l+1) randomizer exponentiations per comparison pre-generated (excluded); informational"}
         # ---- PCIe-inclusive rate (reported at N = 1, never `value`): inputs start in pinned host memory, result returns to the host
         if world == 1:
             host_in = [t.cpu().pin_memory() for t in (x_enc, y_enc, draws.r, draws.delta_a, draws.rhos, draws.rho_z, draws.r_bob_dgk,

@@ -45,10 +45,26 @@ class BatchTrace:
     delta_b_enc: torch.Tensor | None = None
 
 
+def boot_pools(count: int, l: int, alice_paillier: Paillier, alice_dgk: DGK, bob_paillier: Paillier, bob_dgk: DGK,
+               source: str = "os", generator=None) -> None:
+    """Pre-generate every randomizer `count` comparisons consume (the batched form of the two players'
+    _start_randomness_generation: 1 + (l+1) for Alice, 3 + (l+1) for Bob, per comparison)."""
+    alice_paillier.boot_randomness_generation_batch(count, source, generator)
+    alice_dgk.boot_randomness_generation_batch((l + 1) * count, source, generator)
+    bob_paillier.boot_randomness_generation_batch(3 * count, source, generator)
+    bob_dgk.boot_randomness_generation_batch((l + 1) * count, source, generator)
+
+
 def secure_comparison_batch(x_enc: torch.Tensor, y_enc: torch.Tensor, l: int, alice_paillier: Paillier, alice_dgk: DGK,
-                            bob_paillier: Paillier, bob_dgk: DGK, draws: BatchDraws, randomize: bool = True,
+                            bob_paillier: Paillier, bob_dgk: DGK, draws: BatchDraws, randomize: bool | str = True,
                             trace: BatchTrace | None = None) -> torch.Tensor:
-    """[[x <= y]] for B comparisons.  x_enc, y_enc: [B][2nw] Paillier ciphertexts under Bob's key."""
+    """[[x <= y]] for B comparisons.  x_enc, y_enc: [B][2nw] Paillier ciphertexts under Bob's key.
+    randomize: True = every `.randomize()` of the interactive protocol, computed from the injected randomizer inputs in `draws`;
+    "pool" = the same randomizations with pre-generated randomizers from the schemes' device pools (boot_pools), i.e. the
+    online phase of a deployment that generates randomness ahead of time like the reference's background workers;
+    False = the static step chain without randomization."""
+    if randomize == "pool":
+        return _secure_comparison_batch_pooled(x_enc, y_enc, l, alice_paillier, alice_dgk, bob_paillier, bob_dgk, draws)
     # Alice: steps 1, 3
     z_enc, a_plain = Initiator.step_1_batch(x_enc, y_enc, l, alice_paillier, draws.r)
     if randomize:
@@ -74,3 +90,21 @@ def secure_comparison_batch(x_enc: torch.Tensor, y_enc: torch.Tensor, l: int, al
         trace.c_step4h, trace.c_sent, trace.delta_b = c_h, c_sent, delta_b
         trace.zeta_1_enc, trace.zeta_2_enc, trace.delta_b_enc = zeta_1_enc, zeta_2_enc, delta_b_enc
     return result
+
+
+def _secure_comparison_batch_pooled(x_enc, y_enc, l, alice_paillier, alice_dgk, bob_paillier, bob_dgk, draws: BatchDraws) -> torch.Tensor:
+    count = x_enc.shape[0]
+    z_enc, a_plain = Initiator.step_1_batch(x_enc, y_enc, l, alice_paillier, draws.r)
+    z_enc = alice_paillier.randomize_from_pool_batch(z_enc)
+    b_plain = KeyHolder.step_2_batch(z_enc, l, bob_paillier)
+    d_enc, beta_enc = KeyHolder.step_4a_4b_batch(b_plain, l, bob_dgk, bob_paillier, None)
+    nw = d_enc.shape[-1]
+    rnd = bob_dgk.randomize_from_pool_batch(torch.cat([d_enc.reshape(1, count, nw), beta_enc], dim=0).reshape((l + 1) * count, nw))
+    rnd = rnd.reshape(l + 1, count, nw)
+    d_enc, beta_enc = rnd[0].contiguous(), rnd[1:].contiguous()
+    c_h = Initiator.step_4c_to_4h_batch(d_enc, beta_enc, a_plain, draws.delta_a, alice_dgk)
+    c = Initiator.step_4i_batch(c_h, alice_dgk, draws.rhos, draws.permutation, None)
+    c_sent = alice_dgk.randomize_from_pool_batch(c.reshape((l + 1) * count, nw)).reshape(l + 1, count, nw)
+    delta_b = KeyHolder.step_4j_batch(c_sent, bob_dgk)
+    triple = bob_paillier.randomize_from_pool_batch(torch.cat(KeyHolder.step_5_batch(b_plain, delta_b, bob_paillier), dim=0))
+    return Initiator.step_6_7_batch(draws.delta_a, triple[2 * count:], triple[:count], triple[count:2 * count], a_plain, l, alice_paillier)

@@ -277,3 +277,28 @@ def test_freshness_discipline(world):
     assert not c.fresh                 # disclosed
     assert c.peek_value() == asyncio.run(comm.recv("alice", msg_id="m2")).peek_value()
     pai.shut_down()
+
+
+def test_pooled_batch_mode(world):
+    """randomize="pool": randomizers come from pre-booted device pools; results decrypt correctly and the pools are
+    consumed exactly."""
+    from protocols.secure_comparison_amd.batch import boot_pools
+
+    osk, od, eng, bob_p, bob_d = world
+    alice_p, alice_d = bob_p.public_copy(), bob_d.public_copy()
+    for sch in (bob_p, bob_d):
+        sch.shut_down()
+    rng = random.Random(3)
+    B = 4
+    xs = [rng.randrange(1 << L) for _ in range(B)]
+    ys = [rng.randrange(1 << L) for _ in range(B)]
+    drs = [o.draw(rng, L, osk, od, 50) for _ in range(B)]
+    nw = bob_p.mod_n.nwords
+    draws = make_draws(eng, drs, L, nw, (od.u.bit_length() + 31) // 32, 2)
+    boot_pools(B, L, alice_p, alice_d, bob_p, bob_d)
+    with warnings.catch_warnings():
+        warnings.filterwarnings("error", ".*randomness", UserWarning)
+        res = secure_comparison_batch(eng.upload([osk.enc_raw(x) for x in xs], 2 * nw), eng.upload([osk.enc_raw(y) for y in ys], 2 * nw),
+                                      L, alice_p, alice_d, bob_p, bob_d, draws, randomize="pool")
+    assert [osk.dec_raw(v) for v in eng.download(res)] == [int(x <= y) for x, y in zip(xs, ys)]
+    assert all(s._batch_pool.shape[0] == 0 for s in (alice_p, alice_d, bob_p, bob_d))
