@@ -504,3 +504,27 @@ def test_small_and_odd_bit_lengths(engine, keys, l):
     got = engine.download(secure_comparison_batch(engine.upload(x_enc, 2 * nw), engine.upload(y_enc, 2 * nw), l, alice_p, alice_d,
                                                   bob_p, bob_d, draws))
     assert got == expect and [sk.dec_raw(c) for c in got] == [int(x <= y) for x, y in pairs]
+
+
+def test_config3_full_size_properties(engine, keys):
+    """BASELINE configs[2] at full size (B = 65536, l = 32, 2048-bit keys), checked through size-independent properties:
+    Dec(result) == [x <= y] for every comparison; the randomized run and the static (unrandomized) run decrypt alike but differ
+    as ciphertexts; re-randomizing a ciphertext keeps its plaintext; Dec(Enc(m)) round-trips for 65536 plaintexts."""
+    import bench
+    from protocols.secure_comparison_amd.batch import secure_comparison_batch
+
+    sk, dgk = oracle_paillier(keys, 2048), oracle_dgk(keys, "dgk_2048_l32")
+    alice_p, alice_d, bob_p, bob_d = _schemes(engine, sk, dgk, 400)
+    B, l = 65536, 32
+    x, y, x_enc, y_enc, draws = bench.synth_inputs(engine, l, alice_p, bob_p, bob_d, B, 400, seed=5)
+    expect = (x <= y).to(torch.int32)
+    res = secure_comparison_batch(x_enc, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws, randomize=True)
+    dec = bob_p.decrypt_raw_batch(res)
+    assert bool(((dec[:, 0] == expect) & (dec[:, 1:] == 0).all(dim=1)).all().item())
+    static = secure_comparison_batch(x_enc, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws, randomize=False)
+    assert bool((bob_p.decrypt_raw_batch(static)[:, 0] == expect).all().item())
+    assert not bool((static == res).all(dim=1).any().item())              # every ciphertext differs once randomized
+    rer = alice_p.randomize_batch(res, draws.rho_zeta_1)
+    assert bool((bob_p.decrypt_raw_batch(rer)[:, 0] == expect).all().item()) and not bool((rer == res).all(dim=1).any().item())
+    m = draws.r                                                            # 65536 plaintexts below N
+    assert bool((bob_p.decrypt_raw_batch(alice_p.randomize_batch(alice_p.encrypt_raw_batch(m), draws.rho_z)) == m).all().item())
