@@ -277,13 +277,21 @@ def main() -> None:
             cores = min(os.cpu_count() or 1, 16)
             sample = args.cpu_sample or 64 * cores
             py = "/opt/conda/bin/python3.9" if os.path.exists("/opt/conda/bin/python3.9") else sys.executable
+            def cpu_run(interp, count, procs):
+                cp = subprocess.run([interp, os.path.join(ROOT, "oracle", "cpu_baseline.py"), KEYS, f"paillier_{args.pbits}", dname,
+                                     str(count), str(procs), str(args.rbits)], capture_output=True, text=True, timeout=600)
+                return json.loads(cp.stdout.strip().splitlines()[-1])
+
             try:
-                cp = subprocess.run([py, os.path.join(ROOT, "oracle", "cpu_baseline.py"), KEYS, f"paillier_{args.pbits}", dname,
-                                     str(sample), str(cores), str(args.rbits)], capture_output=True, text=True, timeout=600)
-                cb = json.loads(cp.stdout.strip().splitlines()[-1])
+                cb = cpu_run(py, sample, cores)
                 out["cpu_baseline"] = {"value": cb["value"], "unit": "comparisons/s", "cores": cb["cores"], "kind": "port",
                                        "sample": "%d comparisons of the same workload (oracle.compare, %s) over %d processes; %d/%d correct"
                                                  % (cb["count"], cb["arith"], cb["cores"], cb["correct"], cb["count"])}
+                one = cpu_run(py, 8, 1)                       # single-core figure
+                out["cpu_baseline"]["single_core"] = {"value": one["value"], "arith": one["arith"], "sample": one["count"]}
+                if py != sys.executable:                      # and the pure-Python-int path of the default interpreter
+                    pure = cpu_run(sys.executable, 2 * cores, cores)
+                    out["cpu_baseline"]["python_int"] = {"value": pure["value"], "cores": pure["cores"], "arith": pure["arith"], "sample": pure["count"]}
             except Exception as exc:  # pragma: no cover
                 out["cpu_baseline"] = {"value": None, "unit": "comparisons/s", "cores": cores, "kind": "port", "sample": f"failed: {exc}"}
         print(json.dumps(out), flush=True)
