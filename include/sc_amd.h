@@ -76,6 +76,16 @@ int sc_modmul_const(sc_ctx* ctx, int mod, const uint32_t* a_dptr, int cst, uint3
  * x may be wider than the modulus (x_words > nwords): it is reduced first (DGK zero test works mod p). */
 int sc_modexp_shared(sc_ctx* ctx, int mod, int exp, const uint32_t* x_dptr, int x_words,
                      const uint32_t* mul_into_dptr /* nullable */, uint32_t* out_dptr, uint64_t count);
+/* out[i] = x[i]^e mod m^2 [* mul_into[i]] for a modulus that is a perfect square m^2 (Paillier N^2, and p^2 / q^2 in the key
+ * holder's CRT), computed with Montgomery products modulo m only: elements are held as pairs (x0, x1), X = (x0 + x1 m)/R, and
+ * the recorded Montgomery quotient of x0 y0 carries the overflow into the m-part -- 3.5 S^2 multiply-adds per squaring
+ * instead of 6 S^2 (S = limbs of m), identical residues.  mod_m2 must be registered for m^2 with 2 * words(mod_m) words;
+ * x: [count][x_words], x_words <= 4 * words(mod_m) (wider operands are reduced mod m^2 implicitly); out / mul_into:
+ * [count][2 * words(mod_m)].  Available when sc_mod_supports_sq(mod_m) returns 1 (moduli up to 2080 bits), else
+ * SC_ERR_UNSUPPORTED -- use sc_modexp_shared on mod_m2 then.  Same reference call sites as sc_modexp_shared. */
+int sc_modexp_shared_sq(sc_ctx* ctx, int mod_m, int mod_m2, int exp, const uint32_t* x_dptr, int x_words,
+                        const uint32_t* mul_into_dptr /* nullable */, uint32_t* out_dptr, uint64_t count);
+int sc_mod_supports_sq(sc_ctx* ctx, int mod);
 /* flags[i] = (x[i]^e mod n == 1): DGK.is_zero, SC/keyholder.py:249 (e = v_p, n = p). */
 int sc_modexp_shared_isone(sc_ctx* ctx, int mod, int exp, const uint32_t* x_dptr, int x_words,
                            uint8_t* flags_dptr, uint64_t count);

@@ -94,12 +94,15 @@ struct Grp {
   //   MODE 2: like 1 and additionally collects the Montgomery quotient digits into quot[] (lane k
   //           keeps digits k*L..k*L+L-1); quot = -b / n mod R, which is how exact division is done.
   // -------------------------------------------------------------------------------------------
-  template <int MODE>
+  //   COLLECT (default: MODE 2): record the quotient digits.  INIT: the running sum starts at init[] instead of 0
+  //   (MODE 1/2 always start at b).  Both are used by the pair arithmetic modulo n^2 further down.
+  template <int MODE, bool COLLECT = (MODE == 2), bool INIT = false>
   __device__ __forceinline__ void mont(uint32_t (&r)[L], const uint32_t* a_lds, const uint32_t (&b)[L],
-                                       uint32_t (&quot)[L], const uint32_t* a2_lds = nullptr) const {
+                                       uint32_t (&quot)[L], const uint32_t* a2_lds = nullptr,
+                                       const uint32_t* init = nullptr) const {
     uint64_t T[L];
 #pragma unroll
-    for (int i = 0; i < L; i++) T[i] = (MODE == 0 || MODE == 3) ? 0ull : (uint64_t)b[i];
+    for (int i = 0; i < L; i++) T[i] = (MODE == 1 || MODE == 2) ? (uint64_t)b[i] : (INIT ? (uint64_t)init[i] : 0ull);
 #pragma unroll 1
     for (int k = 0; k < G; k++) {
       // L <= 18: fetch the whole block of a-limbs up front (registers to spare).  Larger L: fetch limb by limb so the
@@ -135,7 +138,7 @@ struct Grp {
         }
         uint32_t q = ((uint32_t)T[l] * n0inv) & LMASK;
         q = bcast0<G>(q);
-        if constexpr (MODE == 2) quot[l] = (j == k) ? q : quot[l];
+        if constexpr (COLLECT) quot[l] = (j == k) ? q : quot[l];
 #pragma unroll
         for (int c = 0; c < L; c++) T[(l + c) % L] += (uint64_t)q * n[c];
         const uint64_t t0 = T[l];                 // column 0: its low 29 bits are 0 in lane 0
@@ -189,6 +192,70 @@ struct Grp {
   __device__ __forceinline__ void redc(uint32_t (&r)[L], const uint32_t (&b)[L]) const {
     uint32_t dummy[L];
     mont<1>(r, nullptr, b, dummy);
+  }
+
+  // -------------------------------------------------------------------------------------------
+  // Pair arithmetic modulo n^2 with products modulo n only.  An element X of Z_{n^2} is held as (x0, x1), each a
+  // lazily reduced S-limb integer, with  X = (x0 + x1 n) / R  (mod n^2).  For the product of (x0,x1) and (y0,y1) the
+  // x1 y1 n^2 term vanishes; x0 y0 is Montgomery-reduced with its quotient digits q recorded, x0 y0 + q n = R t
+  // (an integer identity), hence x0 y0 / R = t - q n / R (mod n^2): the "overflow" of the low part is exactly -q,
+  // which is folded into the n-part before ITS reduction:
+  //      z0 = t,   z1 = (x0 y1 + x1 y0 - q) / R  (mod n).
+  // A square costs 0.5 + 1 + 1 + 1 = 3.5 S^2 multiply-adds (S = limbs of n) instead of 6 S^2 for a direct Montgomery
+  // square modulo the 2S-limb n^2; a general product 6 S^2 instead of 8 S^2.  The -q is introduced as the start value
+  // R - q of the running sum (digit complement + 1), which makes the result one too large: corrected by adding n - 1.
+  // Requires L <= 18 (the doubled operand of the square's second pass needs the 1.5 * 2^59 * L < 2^64 column bound).
+  // -------------------------------------------------------------------------------------------
+  __device__ __forceinline__ void pair_fix(uint32_t (&x1)[L], const uint32_t (&v)[L]) const {
+#pragma unroll
+    for (int l = 0; l < L; l++) x1[l] = v[l] + n[l];
+    x1[0] -= (j == 0) ? 1u : 0u;  // n is odd, so limb 0 of v + n is >= 1
+    renorm(x1);
+  }
+  __device__ __forceinline__ void neg_quot_init(uint32_t (&ini)[L], const uint32_t (&q)[L], const uint32_t (&add)[L]) const {
+#pragma unroll
+    for (int l = 0; l < L; l++) ini[l] = add[l] + (LMASK - q[l]);
+    ini[0] += (j == 0) ? 1u : 0u;
+  }
+  // (x0, x1) <- (x0, x1)^2 ;  a_lds / a2_lds hold x0 and 2 x0 (staged by the caller)
+  __device__ __forceinline__ void pair_sqr(uint32_t (&x0)[L], uint32_t (&x1)[L], const uint32_t* a_lds, const uint32_t* a2_lds) const {
+    uint32_t t[L], q[L], ini[L], v[L], zero[L];
+#pragma unroll
+    for (int l = 0; l < L; l++) { q[l] = 0; zero[l] = 0; }
+    mont<3, true, false>(t, a_lds, x0, q, a2_lds);                   // t = (x0^2 + q n) / R
+    neg_quot_init(ini, q, zero);
+    mont<0, false, true>(v, a2_lds, x1, zero, nullptr, ini);         // v = (2 x0 x1 + R - q + q' n) / R
+    pair_fix(x1, v);
+#pragma unroll
+    for (int l = 0; l < L; l++) x0[l] = t[l];
+  }
+  // (x0, x1) <- (x0, x1) * (y0, y1) ;  y0_lds / y1_lds hold the second operand
+  __device__ __forceinline__ void pair_mul(uint32_t (&x0)[L], uint32_t (&x1)[L], const uint32_t* y0_lds, const uint32_t* y1_lds) const {
+    uint32_t t[L], q[L], ini[L], va[L], vb[L], zero[L];
+#pragma unroll
+    for (int l = 0; l < L; l++) { q[l] = 0; zero[l] = 0; }
+    mont<0, true, false>(t, y0_lds, x0, q);                          // t = (x0 y0 + q n) / R
+    neg_quot_init(ini, q, zero);
+    mont<0, false, true>(va, y1_lds, x0, zero, nullptr, ini);        // (x0 y1 + R - q + ..) / R
+    mont<0, false, false>(vb, y0_lds, x1, zero);                     // (x1 y0 + ..) / R
+#pragma unroll
+    for (int l = 0; l < L; l++) va[l] += vb[l];
+    pair_fix(x1, va);
+#pragma unroll
+    for (int l = 0; l < L; l++) x0[l] = t[l];
+  }
+  // (x0, x1) <- (w0, w1) with  w0 + w1 n = (x0 + x1 n) / R  (mod n^2): leaves the pair form (w0, w1 < 2n + 1, lazy)
+  __device__ __forceinline__ void pair_redc(uint32_t (&x0)[L], uint32_t (&x1)[L]) const {
+    uint32_t t[L], q[L], ini[L], v[L];
+#pragma unroll
+    for (int l = 0; l < L; l++) q[l] = 0;
+    mont<2>(t, nullptr, x0, q);                                      // t = (x0 + q n) / R
+    neg_quot_init(ini, q, x1);
+    uint32_t dummy[L];
+    mont<1>(v, nullptr, ini, dummy);                                 // (x1 + R - q + q' n) / R
+    pair_fix(x1, v);
+#pragma unroll
+    for (int l = 0; l < L; l++) x0[l] = t[l];
   }
 
   // -------------------------------------------------------------------------------------------

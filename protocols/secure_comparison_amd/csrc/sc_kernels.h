@@ -222,6 +222,120 @@ __global__ void __launch_bounds__(64, ((L > 18 || G == 16) ? 1 : SC_VM_WAVES)) k
 }
 
 // ---------------------------------------------------------------------------------------------
+// The pair interpreter: exponentiation modulo n^2 carried out with Montgomery products modulo n only (sc_device.h,
+// "pair arithmetic").  Same launch geometry and argument block as k_vm; compiled for the L = 18 configurations.
+// ---------------------------------------------------------------------------------------------
+template <int G, int L, int WB>
+__global__ void __launch_bounds__(64, (G == 16 ? 1 : SC_VM_WAVES)) k_pvm(const VmArgs args) {
+  using GT = Grp<G, L, WB>;
+  constexpr int S = GT::S, NG = GT::NG, SP = GT::SP, WP = GT::WP;
+  __shared__ uint32_t s_a[NG * SP];            // first LDS-side operand  (x0, or y0)
+  __shared__ uint32_t s_a2[NG * SP];           // 2 * x0 (squarings) or y1 (products)
+  __shared__ uint32_t s_w[NG * WP];
+  __shared__ uint32_t s_c[VM_MAX_CONST * SP];
+
+  GT gp;
+  gp.init(args.modctx, args.n0inv);
+  uint32_t* const my_a = s_a + gp.g * SP;
+  uint32_t* const my_a2 = s_a2 + gp.g * SP;
+  uint32_t* const my_w = s_w + gp.g * WP;
+  for (int t = threadIdx.x; t < 2 * S; t += 64) s_c[(t / S) * SP + (t % S)] = args.modctx[S + t];
+  for (int t = threadIdx.x; t < (int)args.nconst_extra * S; t += 64)
+    s_c[(2 + t / S) * SP + (t % S)] = args.consts[t];
+  __syncthreads();
+
+  const uint64_t slot = (uint64_t)blockIdx.x * NG + gp.g;
+  uint32_t* const my_tbl = args.scratch + slot * (uint64_t)args.nscratch * S;
+
+  for (uint64_t base = (uint64_t)blockIdx.x * NG; base < args.count; base += (uint64_t)gridDim.x * NG) {
+    const bool live = base + gp.g < args.count;
+    const uint64_t idx = live ? base + gp.g : args.count - 1;
+    uint32_t x0[L], x1[L];
+#pragma unroll
+    for (int l = 0; l < L; l++) { x0[l] = 0; x1[l] = 0; }
+
+#pragma unroll 1
+    for (uint32_t pc = 0; pc < args.nops; pc++) {
+      const VmOp op = args.prog[pc];
+      const uint32_t opc = op.w0 & 0xff;
+      switch (opc) {
+        case PV_LOADU: {
+          const VmExt& e = args.ext[op.w1 & 0xf];
+          const uint64_t flat = (uint64_t)op.w2 * args.count + idx;
+          const uint32_t woff = op.w3 >> 16;
+          const uint32_t nw = (op.w3 & 0xffff) ? (op.w3 & 0xffff) : e.nwords;
+          gp.load_words(x0, (const uint32_t*)e.ptr + flat * e.stride + woff, nw, my_w);
+#pragma unroll
+          for (int l = 0; l < L; l++) x1[l] = 0;
+          break;
+        }
+        case PV_MULC: {
+          gp.pair_mul(x0, x1, s_c + op.w1 * SP, s_c + (op.w1 + 1) * SP);
+          break;
+        }
+        case PV_MULT: {
+          const uint32_t* src = my_tbl + (uint64_t)(2 * op.w1) * S;
+          __syncthreads();
+#pragma unroll
+          for (int l = 0; l < L; l++) {
+            my_a[gp.j * L + l] = src[gp.j * L + l];
+            my_a2[gp.j * L + l] = src[S + gp.j * L + l];
+          }
+          __syncthreads();
+          gp.pair_mul(x0, x1, my_a, my_a2);
+          break;
+        }
+        case PV_SQR: {
+          __syncthreads();
+          gp.stage(my_a, x0);
+          gp.stage_doubled(my_a2, x0);
+          __syncthreads();
+          gp.pair_sqr(x0, x1, my_a, my_a2);
+          break;
+        }
+        case PV_STT: {
+          uint32_t* dst = my_tbl + (uint64_t)(2 * op.w1) * S;
+          gp.store_limbs(dst, x0);
+          gp.store_limbs(dst + S, x1);
+          break;
+        }
+        case PV_LOADT: {
+          const uint32_t* src = my_tbl + (uint64_t)(2 * op.w1) * S;
+          gp.load_limbs(x0, src);
+          gp.load_limbs(x1, src + S);
+          break;
+        }
+        case PV_ADDT: {
+          const uint32_t* src = my_tbl + (uint64_t)(2 * op.w1) * S;
+          uint32_t t0[L], t1[L];
+          gp.load_limbs(t0, src);
+          gp.load_limbs(t1, src + S);
+#pragma unroll
+          for (int l = 0; l < L; l++) { x0[l] += t0[l]; x1[l] += t1[l]; }
+          gp.renorm(x0);
+          gp.renorm(x1);
+          break;
+        }
+        case PV_OUT: {
+          gp.pair_redc(x0, x1);
+          uint32_t zero[L];
+#pragma unroll
+          for (int l = 0; l < L; l++) zero[l] = 0;
+          gp.normalize(x0, zero);
+          gp.normalize(x1, zero);
+          const VmExt& e0 = args.ext[op.w1 & 0xf];
+          const VmExt& e1 = args.ext[op.w2 & 0xf];
+          gp.store_words((uint32_t*)e0.ptr + idx * e0.stride, e0.nwords, x0, my_a, live);
+          gp.store_words((uint32_t*)e1.ptr + idx * e1.stride, e1.nwords, x1, my_a, live);
+          break;
+        }
+        default: break;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Plain-integer helper kernels on canonical 32-bit words (HBM-bound, one thread per item).
 // ---------------------------------------------------------------------------------------------
 // Alice's plaintext-side values derived from r (SC/initiator.py:250-256, :270, :289, :373, :558-562):

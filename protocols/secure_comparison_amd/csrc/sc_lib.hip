@@ -62,6 +62,31 @@ Big big_shl_mod(const Big& x, const Big& n, int k) {
   v.resize(n.size());
   return v;
 }
+Big big_mul(const Big& a, const Big& b) {  // schoolbook product (set-up time only)
+  Big r(a.size() + b.size(), 0);
+  for (size_t i = 0; i < a.size(); i++) {
+    uint64_t carry = 0;
+    for (size_t j = 0; j < b.size(); j++) {
+      uint64_t v = (uint64_t)a[i] * b[j] + r[i + j] + carry;
+      r[i + j] = (uint32_t)v;
+      carry = v >> 32;
+    }
+    r[i + b.size()] = (uint32_t)carry;
+  }
+  return r;
+}
+// x = q * m + rem by restoring division, bit by bit (set-up time only); q has x.size() words, rem m.size() words
+void big_divmod(const Big& x, const Big& m, Big* q, Big* rem) {
+  Big r(m.size() + 1, 0), mm = m; mm.push_back(0);
+  q->assign(x.size(), 0);
+  for (int bit = 32 * (int)x.size() - 1; bit >= 0; bit--) {
+    uint32_t carry = (x[bit >> 5] >> (bit & 31)) & 1;
+    for (size_t i = 0; i < r.size(); i++) { uint32_t nc = r[i] >> 31; r[i] = (r[i] << 1) | carry; carry = nc; }
+    if (big_cmp(r, mm) >= 0) { big_sub(r, mm); (*q)[bit >> 5] |= 1u << (bit & 31); }
+  }
+  r.resize(m.size());
+  *rem = r;
+}
 std::vector<uint32_t> to_limbs(const Big& x, int S, int W) {
   std::vector<uint32_t> out(S, 0);
   const uint32_t mask = (1u << W) - 1;
@@ -118,6 +143,8 @@ struct sc_ctx {
   std::map<int, std::pair<void*, size_t>> tmp;          // grow-only temporaries, reused across calls (same stream => ordered)
   std::map<std::vector<uint32_t>, uint32_t*> nwords_cache;  // device copy of {n, (n-1)/2} for the plain-word kernels
   std::map<int, int> kred_cache;                            // mod -> constant id of 2^(32 nwords) (wide-operand reduction)
+  std::map<std::pair<int, std::vector<uint32_t>>, int> const_by_value;  // (mod, residue) -> constant id
+  std::map<int, uint32_t*> pair_consts;                     // mod -> 4 limb arrays: pair(R^2), pair(B R) for the pair arithmetic
 };
 
 namespace {
@@ -163,7 +190,7 @@ int tmp_buf(sc_ctx* ctx, int slot, size_t bytes, void** out) {
   *out = e.first;
   return SC_OK;
 }
-enum TmpSlot { TMP_PARK = 1, TMP_XGCD_STATUS = 2, TMP_CRT = 3, TMP_INV_BASE = 16 /* + 2*depth, + 2*depth+1 */ };
+enum TmpSlot { TMP_PARK = 1, TMP_XGCD_STATUS = 2, TMP_CRT = 3, TMP_PAIR = 4, TMP_INV_BASE = 16 /* + 2*depth, + 2*depth+1 */ };
 
 // device copy of n | (n-1)/2 as canonical words (plain-word kernels)
 int device_n_half(sc_ctx* ctx, const uint32_t* n_hptr, int nw, uint32_t** out) {
@@ -308,6 +335,53 @@ int run_vm(sc_ctx* ctx, int mod, const Prog& p, const VmExt* exts, int next, uin
 #undef SC_CASE
   if (rc == SC_ERR_UNSUPPORTED) return fail(ctx, rc, "no kernel configuration for G=%d L=%d", m.G, m.L);
   return rc;
+}
+
+template <int G>
+int launch_pvm_cfg(sc_ctx* ctx, const VmArgs& a) {
+  constexpr int L = 18, NG = 64 / G;
+  const int key = 1000 + G;
+  auto it = ctx->occ_cache.find(key);
+  int occ;
+  if (it == ctx->occ_cache.end()) {
+    int nb = 0;
+    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_pvm<G, L, 29>, 64, 0));
+    occ = std::max(1, std::min(nb, 16));
+    ctx->occ_cache[key] = occ;
+  } else {
+    occ = it->second;
+  }
+  uint64_t need = (a.count + NG - 1) / NG;
+  uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(need, (uint64_t)ctx->num_cu * occ));
+  int rc = ensure_scratch(ctx, (size_t)grid * NG * a.nscratch * (G * L) * 4);
+  if (rc) return rc;
+  VmArgs args = a;
+  args.scratch = ctx->scratch;
+  hipLaunchKernelGGL((k_pvm<G, L, 29>), dim3(grid), dim3(64), 0, ctx->stream, args);
+  HIPCHK(ctx, hipGetLastError());
+  return SC_OK;
+}
+
+// pair programs: nscratch counts limb-form entries (2 per pair entry); macs = multiply-adds per item
+int run_pvm(sc_ctx* ctx, int mod, const Prog& p, const VmExt* exts, int next, uint64_t count) {
+  if (count == 0) return SC_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const Mod& m = ctx->mods[mod];
+  VmArgs a;
+  memset(&a, 0, sizeof a);
+  a.modctx = m.d_ctx; a.consts = p.d_consts; a.prog = p.d_ops; a.count = count; a.n0inv = m.n0inv;
+  a.nops = p.nops; a.nconst_extra = p.nconst; a.nscratch = p.nscratch;
+  for (int i = 0; i < next; i++) a.ext[i] = exts[i];
+  ctx->mac_counter += (double)count * p.muls_per_item;   // pair programs carry their exact multiply-add count here
+  if (m.L != 18 || m.W != 29) return fail(ctx, SC_ERR_UNSUPPORTED, "pair arithmetic needs an L = 18 configuration");
+  switch (m.G) {
+    case 1: return launch_pvm_cfg<1>(ctx, a);
+    case 2: return launch_pvm_cfg<2>(ctx, a);
+    case 4: return launch_pvm_cfg<4>(ctx, a);
+    case 8: return launch_pvm_cfg<8>(ctx, a);
+    case 16: return launch_pvm_cfg<16>(ctx, a);
+  }
+  return fail(ctx, SC_ERR_UNSUPPORTED, "no pair kernel for G=%d", m.G);
 }
 
 VmExt mk_ext(const void* p, uint32_t stride, uint32_t nwords, uint64_t limit = ~0ull) {
@@ -487,6 +561,18 @@ int sc_const_create(sc_ctx* ctx, int mod, const uint32_t* v_hptr, int nwords, in
 }  // extern "C"
 
 namespace {
+// registers the residue v (host words) as a constant of `mod` once per (mod, value)
+int sc_const_create_cached(sc_ctx* ctx, int mod, const Big& v, int* out_cid) {
+  auto key = std::make_pair(mod, v);
+  auto it = ctx->const_by_value.find(key);
+  if (it != ctx->const_by_value.end()) { *out_cid = it->second; return SC_OK; }
+  int cid;
+  int rc = sc_const_create(ctx, mod, v.data(), (int)v.size(), &cid);
+  if (rc) return rc;
+  ctx->const_by_value[key] = cid;
+  *out_cid = cid;
+  return SC_OK;
+}
 // Montgomery form of 2^(32 * nwords): multiplying by it shifts a residue up by one operand width
 int get_const_kred(sc_ctx* ctx, int mod, int* out_cid) {
   const Mod& m = ctx->mods[mod];
@@ -968,6 +1054,128 @@ int sc_crt_combine(sc_ctx* ctx, int mod_p, int mod_full, int cst_k, int cst_negk
   }
   VmExt ex[3] = {mk_ext(d_t, mp.nwords, mp.nwords), mk_ext(a_q, a_q_words, a_q_words), mk_ext(out, mf.nwords, mf.nwords)};
   return run_vm(ctx, mod_full, it2->second, ex, 3, count);
+}
+
+// Limb-form constant pairs of a modulus m for the pair arithmetic: pair(R^2) embeds an integer (u,0) -> u; pair(B R) is
+// the radix B = 2^(32 nwords) of the operand chunks.  Each pair (c0, c1) satisfies c0 + c1 m = value (mod m^2), c0, c1 < m.
+static int get_pair_consts(sc_ctx* ctx, int mod, uint32_t** out) {
+  auto it = ctx->pair_consts.find(mod);
+  if (it != ctx->pair_consts.end()) { *out = it->second; return SC_OK; }
+  const Mod& m = ctx->mods[mod];
+  Big m2 = big_mul(m.n, m.n);
+  Big one(m2.size(), 0); one[0] = 1;
+  Big r2 = big_shl_mod(one, m2, 2 * m.W * m.S);                       // R^2 mod m^2
+  Big br = big_shl_mod(one, m2, m.W * m.S + 32 * m.nwords);           // B R mod m^2
+  std::vector<uint32_t> limbs;
+  for (const Big* v : {&r2, &br}) {
+    Big q, rem;
+    big_divmod(*v, m.n, &q, &rem);
+    q.resize(m.nwords);
+    for (const Big* part : {&rem, &q}) { auto l = to_limbs(*part, m.S, m.W); limbs.insert(limbs.end(), l.begin(), l.end()); }
+  }
+  uint32_t* d = nullptr;
+  int rc = upload(ctx, limbs.data(), limbs.size() * 4, (void**)&d);
+  if (rc) return rc;
+  ctx->pair_consts[mod] = d;
+  *out = d;
+  return SC_OK;
+}
+
+int sc_mod_supports_sq(sc_ctx* ctx, int mod) {
+  if (!valid_mod(ctx, mod)) return SC_ERR_ARG;
+  return (ctx->mods[mod].L == 18 && ctx->mods[mod].W == 29) ? 1 : 0;
+}
+
+int sc_modexp_shared_sq(sc_ctx* ctx, int mod_m, int mod_m2, int exp, const uint32_t* x, int x_words, const uint32_t* mul_into,
+                        uint32_t* out, uint64_t count) {
+  if (ctx && count == 0) return SC_OK;
+  if (!valid_mod(ctx, mod_m) || !valid_mod(ctx, mod_m2) || exp < 0 || exp >= (int)ctx->exps.size() || !x || !out || x_words <= 0)
+    return fail(ctx, SC_ERR_ARG, "sc_modexp_shared_sq: bad argument");
+  const Mod& m = ctx->mods[mod_m];
+  const Mod& m2 = ctx->mods[mod_m2];
+  if (m.L != 18 || m.W != 29) return fail(ctx, SC_ERR_UNSUPPORTED, "sc_modexp_shared_sq: modulus needs an L = 18 configuration");
+  {
+    Big sq = big_mul(m.n, m.n);
+    sq.resize(std::max(sq.size(), m2.n.size()), 0);
+    Big other = m2.n; other.resize(sq.size(), 0);
+    if (big_cmp(sq, other) != 0) return fail(ctx, SC_ERR_ARG, "sc_modexp_shared_sq: mod_m2 is not the square of mod_m");
+  }
+  if (x_words > 4 * m.nwords) return fail(ctx, SC_ERR_ARG, "sc_modexp_shared_sq: operand wider than 4 chunks");
+  const Exp& ex = ctx->exps[exp];
+  const int wm = m.nwords + 1;                                           // words of the raw pair halves (< 2m + 1)
+  uint32_t* d_w;
+  { int rc0 = tmp_buf(ctx, TMP_PAIR, (size_t)count * wm * 4 * 2, (void**)&d_w); if (rc0) return rc0; }
+  uint32_t* d_w1 = d_w + (size_t)count * wm;
+  // ---- launch 1: pair exponentiation in the m context
+  std::string k1 = "psq:" + std::to_string(mod_m) + ":" + std::to_string(exp) + ":" + std::to_string(x_words);
+  auto it1 = ctx->progs.find(k1);
+  if (it1 == ctx->progs.end()) {
+    std::vector<VmOp> ops;
+    uint32_t nsc = 2;
+    double macs = 0;
+    const double S2 = (double)m.S * m.S, SQ = S2 + (double)m.G * m.L * (m.L + 1) / 2.0 + 2.0 * S2, MU = 6.0 * S2;
+    auto emit = [&](uint32_t opc, uint32_t w1 = 0, uint32_t w2 = 0, uint32_t w3 = 0) { ops.push_back(VmOp{opc, w1, w2, w3}); };
+    auto touch = [&](uint32_t e) { nsc = std::max(nsc, 2 * e + 2); };
+    // embed the operand: Horner over chunks of nwords words; constants: LDS 2,3 = pair(R^2), 4,5 = pair(B R)
+    const int nch = (x_words + m.nwords - 1) / m.nwords;
+    const uint32_t TMP_E = 0;                                            // scratch pair entry used while embedding
+    for (int t = nch - 1; t >= 0; t--) {
+      const int nw = std::min(m.nwords, x_words - t * m.nwords);
+      if (t != nch - 1) { emit(PV_MULC, 4); macs += MU; emit(PV_STT, TMP_E); touch(TMP_E); }
+      emit(PV_LOADU, 0, 0, ((uint32_t)(t * m.nwords) << 16) | (uint32_t)nw);
+      emit(PV_MULC, 2); macs += MU;
+      if (t != nch - 1) emit(PV_ADDT, TMP_E);
+    }
+    // sliding-window exponentiation on pairs (same schedule as emit_pow_shared)
+    const int bits = ex.bits;
+    if (bits == 0) return fail(ctx, SC_ERR_ARG, "sc_modexp_shared_sq: zero exponent");
+    const int w = best_window(bits), NT = 1 << (w - 1);
+    const uint32_t T0 = 1;                                               // table entries T0 .. T0+NT-1, x^2 at T0+NT
+    emit(PV_STT, T0); touch(T0);
+    if (NT > 1) {
+      emit(PV_SQR); macs += SQ; emit(PV_STT, T0 + NT); touch(T0 + NT);
+      for (int k = 1; k < NT; k++) { emit(PV_LOADT, T0 + k - 1); emit(PV_MULT, T0 + NT); macs += MU; emit(PV_STT, T0 + k); touch(T0 + k); }
+    }
+    bool first = true;
+    int i = bits - 1;
+    while (i >= 0) {
+      if (!ebit(ex.e, i)) { emit(PV_SQR); macs += SQ; i--; continue; }
+      int jj = std::max(0, i - w + 1);
+      while (!ebit(ex.e, jj)) jj++;
+      int v = 0;
+      for (int k = i; k >= jj; k--) v = (v << 1) | ebit(ex.e, k);
+      if (first) { emit(PV_LOADT, T0 + (v - 1) / 2); first = false; }
+      else { for (int k = 0; k < i - jj + 1; k++) { emit(PV_SQR); macs += SQ; } emit(PV_MULT, T0 + (v - 1) / 2); macs += MU; }
+      i = jj - 1;
+    }
+    emit(PV_OUT, 1, 2); macs += 2.0 * S2;
+    emit(PV_END);
+    Prog p;
+    p.nops = (uint32_t)ops.size(); p.nscratch = nsc; p.nconst = 4; p.muls_per_item = macs;
+    int rc = upload(ctx, ops.data(), ops.size() * sizeof(VmOp), (void**)&p.d_ops); if (rc) return rc;
+    rc = get_pair_consts(ctx, mod_m, &p.d_consts); if (rc) return rc;
+    it1 = ctx->progs.emplace(k1, p).first;
+  }
+  {
+    VmExt ex3[3] = {mk_ext(x, x_words, x_words), mk_ext(d_w, wm, wm), mk_ext(d_w1, wm, wm)};
+    int rc = run_pvm(ctx, mod_m, it1->second, ex3, 3, count); if (rc) return rc;
+  }
+  // ---- launch 2 (m^2 context): out = (w0 + w1 m) [* mul_into] mod m^2
+  int cst_m;
+  { int rc = sc_const_create_cached(ctx, mod_m2, m.n, &cst_m); if (rc) return rc; }
+  std::string k2 = "psq2:" + std::to_string(mod_m2) + ":" + std::to_string(cst_m) + ":" + std::to_string(wm) + ":" + std::to_string(mul_into ? 1 : 0);
+  auto it2 = ctx->progs.find(k2);
+  if (it2 == ctx->progs.end()) {
+    Builder bd; const int cm = bd.use_const(cst_m);
+    bd.loadw(1, 0, 0, wm); bd.mul_const(cm);           // w1 * m  (mod m^2)
+    bd.addw(0, 0, 0, wm);                              // + w0
+    if (mul_into) { bd.mul_const(0); bd.mul_extw(2); } // to Montgomery form, times the ciphertext
+    bd.storew(3); bd.end();
+    Prog p; int rc = finalize_prog(ctx, m2, bd, &p); if (rc) return rc;
+    it2 = ctx->progs.emplace(k2, p).first;
+  }
+  VmExt ex4[4] = {mk_ext(d_w, wm, wm), mk_ext(d_w1, wm, wm), mk_ext(mul_into, m2.nwords, m2.nwords), mk_ext(out, m2.nwords, m2.nwords)};
+  return run_vm(ctx, mod_m2, it2->second, ex4, 4, count);
 }
 
 int sc_peak_probe(sc_ctx* ctx, double* out_mac_per_s) {

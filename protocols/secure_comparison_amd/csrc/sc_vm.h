@@ -28,6 +28,20 @@ enum VmOpcode : uint32_t {
   OP_NEG = 15,       // ACC = (n - ACC) mod n, exact limbs
 };
 
+// Opcodes of the pair interpreter k_pvm (arithmetic modulo n^2 with products modulo n, sc_device.h "pair arithmetic").
+// State: the pair (ACC0, ACC1); scratch pair entry e occupies limb-form entries 2e and 2e+1 of the slot's table.
+enum PvOpcode : uint32_t {
+  PV_END = 0,
+  PV_LOADU = 1,   // ACC0 = words ext[w1] at off w2 (word offset w3>>16, nwords w3&0xffff), ACC1 = 0   (pair of u / R)
+  PV_MULC = 2,    // pair *= constant pair held in LDS constants w1, w1+1
+  PV_MULT = 3,    // pair *= scratch pair entry w1
+  PV_SQR = 4,     // pair = pair^2
+  PV_STT = 5,     // scratch pair entry w1 = pair
+  PV_LOADT = 6,   // pair = scratch pair entry w1
+  PV_ADDT = 7,    // pair += scratch pair entry w1 (component-wise, lazy)
+  PV_OUT = 8,     // leave the pair form and store: ACC0 -> ext[w1], ACC1 -> ext[w2] as exact words (not reduced mod n)
+};
+
 enum VmAKind : uint32_t {
   AK_CONST = 0,   // w1 = LDS constant index (0 = R^2 mod n, 1 = R mod n, 2.. = extra constants)
   AK_ACC = 1,     // the accumulator itself (squaring)

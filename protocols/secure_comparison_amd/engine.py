@@ -171,6 +171,20 @@ class Engine:
                                               self._ptr(mul_into), self._ptr(out), count))
         return out
 
+    def supports_sq(self, mod: Modulus) -> bool:
+        """Can x^e mod m^2 be computed with products modulo m (pair arithmetic) for this modulus?"""
+        return self.lib.sc_mod_supports_sq(self.ctx, mod.id) == 1
+
+    def modexp_shared_sq(self, mod_m: Modulus, mod_m2: Modulus, x: torch.Tensor, e: int, mul_into: torch.Tensor | None = None,
+                         out: torch.Tensor | None = None) -> torch.Tensor:
+        """x^e mod m^2 [* mul_into] via pair arithmetic modulo m (identical residues, ~0.6x the multiply-adds)."""
+        count = x.shape[0]
+        out = self.empty(count, mod_m2.nwords) if out is None else out
+        self._sync_stream()
+        self._check(self.lib.sc_modexp_shared_sq(self.ctx, mod_m.id, mod_m2.id, self.exponent(e), self._ptr(x), x.shape[-1],
+                                                 self._ptr(mul_into), self._ptr(out), count))
+        return out
+
     def modexp_shared_isone(self, mod: Modulus, x: torch.Tensor, e: int) -> torch.Tensor:
         count = x.shape[0]
         flags = torch.empty((count,), dtype=torch.uint8, device=self.device)

@@ -257,8 +257,10 @@ class Paillier(_Scheme):
 
     _ct_class = PaillierCiphertext
 
-    def __init__(self, n: int, p: int | None = None, q: int | None = None, engine=None, use_crt: bool = True) -> None:
+    def __init__(self, n: int, p: int | None = None, q: int | None = None, engine=None, use_crt: bool = True,
+                 use_pairs: bool = True) -> None:
         super().__init__(engine)
+        self.use_pairs = use_pairs  # exponentiations modulo N^2 / p^2 / q^2 through pair arithmetic modulo N / p / q
         self.public_key = _PublicKey(n=n, n_squared=n * n, g=n + 1)
         self.secret_key = None
         self.use_crt = use_crt
@@ -332,6 +334,8 @@ class Paillier(_Scheme):
         if self.secret_key is not None and self.use_crt:
             rn = self._crt_pow_n(rho)
             return rn if c is None else e.modmul(self.mod_n2, c, rn)
+        if self.use_pairs and e.supports_sq(self.mod_n):
+            return e.modexp_shared_sq(self.mod_n, self.mod_n2, rho, n, mul_into=c)   # arithmetic modulo N only
         if rho.shape[-1] != self.mod_n2.nwords:
             rho = torch.nn.functional.pad(rho, (0, self.mod_n2.nwords - rho.shape[-1]))
         return e.modexp_shared(self.mod_n2, rho, n, mul_into=c)
@@ -343,7 +347,10 @@ class Paillier(_Scheme):
         e = self.engine
         if self.use_crt:
             return self._crt_decrypt(c)
-        x = e.modexp_shared(self.mod_n2, c, self.secret_key.lambda_)
+        if self.use_pairs and e.supports_sq(self.mod_n):
+            x = e.modexp_shared_sq(self.mod_n, self.mod_n2, c, self.secret_key.lambda_)
+        else:
+            x = e.modexp_shared(self.mod_n2, c, self.secret_key.lambda_)
         return e.paillier_l_mul(self.mod_n, self.secret_key.mu, x)
 
     def add_batch(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
@@ -380,7 +387,10 @@ class Paillier(_Scheme):
         for name, pr in (("p", p), ("q", q)):
             c = crt[name]
             y = e.modexp_shared(c["m1"], rho, c["e_small"])                 # (rho mod p)^(q mod p-1) mod p  (wide input reduced)
-            parts[name] = e.modexp_shared(c["m2"], torch.nn.functional.pad(y, (0, c["m2"].nwords - y.shape[-1])), pr)
+            if self.use_pairs and e.supports_sq(c["m1"]):
+                parts[name] = e.modexp_shared_sq(c["m1"], c["m2"], y, pr)                # y^p mod p^2 with products mod p
+            else:
+                parts[name] = e.modexp_shared(c["m2"], torch.nn.functional.pad(y, (0, c["m2"].nwords - y.shape[-1])), pr)
         return e.crt_combine(crt["p"]["m2"], self.mod_n2, q * q, parts["p"], parts["q"])
 
     def _crt_decrypt(self, c: torch.Tensor) -> torch.Tensor:
@@ -389,7 +399,10 @@ class Paillier(_Scheme):
         ms = {}
         for name, pr in (("p", p), ("q", q)):
             cc = crt[name]
-            x = e.modexp_shared(cc["m2"], c, pr - 1)                       # c^(p-1) mod p^2 (wide input reduced)
+            if self.use_pairs and e.supports_sq(cc["m1"]):
+                x = e.modexp_shared_sq(cc["m1"], cc["m2"], c, pr - 1)       # c^(p-1) mod p^2 with products mod p
+            else:
+                x = e.modexp_shared(cc["m2"], c, pr - 1)                   # c^(p-1) mod p^2 (wide input reduced)
             ms[name] = e.paillier_l_mul(cc["m1"], cc["h"], x)              # L_p(x) * h_p mod p
         return e.crt_combine(crt["p"]["m1"], self.mod_n, q, ms["p"], ms["q"])
 

@@ -76,6 +76,12 @@ class OracleEngine:
             r = [a * b % mod.n for a, b in zip(r, self._ints(mul_into))]
         return self.upload(r, mod.nwords)
 
+    def supports_sq(self, mod):
+        return True
+
+    def modexp_shared_sq(self, mod_m, mod_m2, x, e, mul_into=None, out=None):
+        return self.modexp_shared(mod_m2, x, e, mul_into, out)
+
     def modexp_shared_isone(self, mod, x, e):
         return torch.tensor([int(pow(v, e, mod.n) == 1) for v in self._ints(x)], dtype=torch.uint8)
 
