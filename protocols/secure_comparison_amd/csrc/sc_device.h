@@ -96,7 +96,7 @@ struct Grp {
   // -------------------------------------------------------------------------------------------
   //   COLLECT (default: MODE 2): record the quotient digits.  INIT: the running sum starts at init[] instead of 0
   //   (MODE 1/2 always start at b).  Both are used by the pair arithmetic modulo n^2 further down.
-  template <int MODE, bool COLLECT = (MODE == 2), bool INIT = false>
+  template <int MODE, bool COLLECT = (MODE == 2), bool INIT = false, bool PRELOAD_A = true>
   __device__ __forceinline__ void mont(uint32_t (&r)[L], const uint32_t* a_lds, const uint32_t (&b)[L],
                                        uint32_t (&quot)[L], const uint32_t* a2_lds = nullptr,
                                        const uint32_t* init = nullptr) const {
@@ -107,7 +107,7 @@ struct Grp {
     for (int k = 0; k < G; k++) {
       // L <= 18: fetch the whole block of a-limbs up front (registers to spare).  Larger L: fetch limb by limb so the
       // block does not pin another L registers (the L = 27 configurations otherwise spill into scratch).
-      constexpr bool PRELOAD = (L <= 18);
+      constexpr bool PRELOAD = (L <= 18) && PRELOAD_A;
       uint32_t av[PRELOAD ? L : 1];
       if constexpr (MODE == 0 && PRELOAD) {
 #pragma unroll
@@ -206,56 +206,54 @@ struct Grp {
   // R - q of the running sum (digit complement + 1), which makes the result one too large: corrected by adding n - 1.
   // Requires L <= 18 (the doubled operand of the square's second pass needs the 1.5 * 2^59 * L < 2^64 column bound).
   // -------------------------------------------------------------------------------------------
-  __device__ __forceinline__ void pair_fix(uint32_t (&x1)[L], const uint32_t (&v)[L]) const {
+  // x1 <- x1 + n - 1 (lazy), the correction for the start value R - q
+  __device__ __forceinline__ void pair_fix(uint32_t (&x1)[L]) const {
 #pragma unroll
-    for (int l = 0; l < L; l++) x1[l] = v[l] + n[l];
+    for (int l = 0; l < L; l++) x1[l] += n[l];
     x1[0] -= (j == 0) ? 1u : 0u;  // n is odd, so limb 0 of v + n is >= 1
     renorm(x1);
   }
-  __device__ __forceinline__ void neg_quot_init(uint32_t (&ini)[L], const uint32_t (&q)[L], const uint32_t (&add)[L]) const {
+  // q <- digits of R - q (+ add[]): the start value that injects -q into the next reduction
+  __device__ __forceinline__ void neg_quot_init(uint32_t (&q)[L]) const {
 #pragma unroll
-    for (int l = 0; l < L; l++) ini[l] = add[l] + (LMASK - q[l]);
-    ini[0] += (j == 0) ? 1u : 0u;
+    for (int l = 0; l < L; l++) q[l] = LMASK - q[l];
+    q[0] += (j == 0) ? 1u : 0u;
   }
-  // (x0, x1) <- (x0, x1)^2 ;  a_lds / a2_lds hold x0 and 2 x0 (staged by the caller)
+  // (x0, x1) <- (x0, x1)^2 ;  a_lds / a2_lds hold x0 and 2 x0 (staged by the caller).  Outputs alias the inputs on purpose
+  // (a result is only written after the last read of its operand) to keep the register footprint at x0, x1, q.
   __device__ __forceinline__ void pair_sqr(uint32_t (&x0)[L], uint32_t (&x1)[L], const uint32_t* a_lds, const uint32_t* a2_lds) const {
-    uint32_t t[L], q[L], ini[L], v[L], zero[L];
+    uint32_t q[L];
 #pragma unroll
-    for (int l = 0; l < L; l++) { q[l] = 0; zero[l] = 0; }
-    mont<3, true, false>(t, a_lds, x0, q, a2_lds);                   // t = (x0^2 + q n) / R
-    neg_quot_init(ini, q, zero);
-    mont<0, false, true>(v, a2_lds, x1, zero, nullptr, ini);         // v = (2 x0 x1 + R - q + q' n) / R
-    pair_fix(x1, v);
-#pragma unroll
-    for (int l = 0; l < L; l++) x0[l] = t[l];
+    for (int l = 0; l < L; l++) q[l] = 0;
+    mont<3, true, false>(x0, a_lds, x0, q, a2_lds);                  // x0 <- t = (x0^2 + q n) / R
+    neg_quot_init(q);
+    mont<0, false, true, false>(x1, a2_lds, x1, q, nullptr, q);      // x1 <- (2 x0 x1 + R - q + q' n) / R
+    pair_fix(x1);
   }
   // (x0, x1) <- (x0, x1) * (y0, y1) ;  y0_lds / y1_lds hold the second operand
   __device__ __forceinline__ void pair_mul(uint32_t (&x0)[L], uint32_t (&x1)[L], const uint32_t* y0_lds, const uint32_t* y1_lds) const {
-    uint32_t t[L], q[L], ini[L], va[L], vb[L], zero[L];
+    uint32_t t[L], q[L];
 #pragma unroll
-    for (int l = 0; l < L; l++) { q[l] = 0; zero[l] = 0; }
-    mont<0, true, false>(t, y0_lds, x0, q);                          // t = (x0 y0 + q n) / R
-    neg_quot_init(ini, q, zero);
-    mont<0, false, true>(va, y1_lds, x0, zero, nullptr, ini);        // (x0 y1 + R - q + ..) / R
-    mont<0, false, false>(vb, y0_lds, x1, zero);                     // (x1 y0 + ..) / R
+    for (int l = 0; l < L; l++) q[l] = 0;
+    mont<0, true, false, false>(t, y0_lds, x0, q);                   // t = (x0 y0 + q n) / R
+    neg_quot_init(q);
+    mont<0, false, true, false>(x0, y1_lds, x0, q, nullptr, q);      // x0 <- (x0 y1 + R - q + ..) / R
+    mont<0, false, false, false>(x1, y0_lds, x1, q);                 // x1 <- (x1 y0 + ..) / R
 #pragma unroll
-    for (int l = 0; l < L; l++) va[l] += vb[l];
-    pair_fix(x1, va);
-#pragma unroll
-    for (int l = 0; l < L; l++) x0[l] = t[l];
+    for (int l = 0; l < L; l++) { x1[l] += x0[l]; x0[l] = t[l]; }
+    pair_fix(x1);
   }
   // (x0, x1) <- (w0, w1) with  w0 + w1 n = (x0 + x1 n) / R  (mod n^2): leaves the pair form (w0, w1 < 2n + 1, lazy)
   __device__ __forceinline__ void pair_redc(uint32_t (&x0)[L], uint32_t (&x1)[L]) const {
-    uint32_t t[L], q[L], ini[L], v[L];
+    uint32_t q[L];
 #pragma unroll
     for (int l = 0; l < L; l++) q[l] = 0;
-    mont<2>(t, nullptr, x0, q);                                      // t = (x0 + q n) / R
-    neg_quot_init(ini, q, x1);
-    uint32_t dummy[L];
-    mont<1>(v, nullptr, ini, dummy);                                 // (x1 + R - q + q' n) / R
-    pair_fix(x1, v);
+    mont<2>(x0, nullptr, x0, q);                                     // x0 <- (x0 + q n) / R
+    neg_quot_init(q);
 #pragma unroll
-    for (int l = 0; l < L; l++) x0[l] = t[l];
+    for (int l = 0; l < L; l++) x1[l] += q[l];
+    mont<1>(x1, nullptr, x1, q);                                     // x1 <- (x1 + R - q + q' n) / R
+    pair_fix(x1);
   }
 
   // -------------------------------------------------------------------------------------------

@@ -528,3 +528,50 @@ def test_config3_full_size_properties(engine, keys):
     assert bool((bob_p.decrypt_raw_batch(rer)[:, 0] == expect).all().item()) and not bool((rer == res).all(dim=1).any().item())
     m = draws.r                                                            # 65536 plaintexts below N
     assert bool((bob_p.decrypt_raw_batch(alice_p.randomize_batch(alice_p.encrypt_raw_batch(m), draws.rho_z)) == m).all().item())
+
+
+@pytest.mark.parametrize("bits", [256, 512, 1024, 2048])
+def test_pair_arithmetic_modexp(engine, bits):
+    """sc_modexp_shared_sq (x^e mod m^2 with Montgomery products modulo m only) against Python pow: operands of 1, 2 and 4
+    chunks (wider than m^2 included), edge operands 0, 1, m, m - 1, m^2 - 1, exponents 1, 2, 3, m, m - 1 and random, mul_into."""
+    rng = random.Random(bits)
+    m = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+    mm, mm2 = engine.modulus(m), engine.modulus(m * m, 2 * ((bits + 31) // 32))
+    assert engine.supports_sq(mm)
+    B = 24
+    for mult, xs in ((1, [rng.randrange(m) for _ in range(B)]), (2, [rng.randrange(m * m) for _ in range(B)]), (4, [rng.getrandbits(4 * bits) for _ in range(B)])):
+        xs[:5] = [1, 0, m - 1, m if mult > 1 else 2, (m * m - 1) if mult > 1 else m - 2]
+        t = engine.upload(xs, mult * mm.nwords)
+        for e in (1, 2, 3, m, m - 1, rng.getrandbits(bits) | 1, (1 << 77) - 1):
+            assert engine.download(engine.modexp_shared_sq(mm, mm2, t, e)) == [pow(x, e, m * m) for x in xs], (bits, mult, e.bit_length())
+        cs = [rng.randrange(m * m) for _ in range(B)]
+        got = engine.download(engine.modexp_shared_sq(mm, mm2, t, m, mul_into=engine.upload(cs, mm2.nwords)))
+        assert got == [pow(x, m, m * m) * c % (m * m) for x, c in zip(xs, cs)]
+    n = (1 << bits) - 1                      # all-ones limbs: the largest column sums of the pair passes
+    while n % 3 == 0 or n % 5 == 0:
+        n -= 2
+    mn, mn2 = engine.modulus(n), engine.modulus(n * n, 2 * ((bits + 31) // 32))
+    xs = [n * n - 1, n - 1, n * n - n, (1 << (2 * bits - 1)) - 1]
+    assert engine.download(engine.modexp_shared_sq(mn, mn2, engine.upload(xs, 2 * mn.nwords), (1 << 100) - 1)) == [pow(x, (1 << 100) - 1, n * n) for x in xs]
+    with pytest.raises(Exception):
+        engine.modexp_shared_sq(mm, mn2, t, 3)   # mod_m2 is not the square of mod_m
+
+
+def test_paillier_paths_agree(engine, keys):
+    """Pair arithmetic on/off and CRT on/off give identical ciphertexts and plaintexts (2048-bit key)."""
+    from protocols.secure_comparison_amd import Paillier
+
+    sk = oracle_paillier(keys, 2048)
+    rng = random.Random(4)
+    B = 30
+    ms = [rng.randrange(sk.n) for _ in range(B)]
+    rhos = [1 + rng.randrange(sk.n - 1) for _ in range(B)]
+    outs = []
+    for use_crt in (False, True):
+        for use_pairs in (False, True):
+            p = Paillier(sk.n, sk.p, sk.q, engine=engine, use_crt=use_crt, use_pairs=use_pairs)
+            nw = p.mod_n.nwords
+            rnd = p.randomize_batch(p.encrypt_raw_batch(engine.upload(ms, nw)), engine.upload(rhos, nw))
+            outs.append((engine.download(rnd), engine.download(p.decrypt_raw_batch(rnd))))
+    assert all(o_ == outs[0] for o_ in outs) and outs[0][1] == ms
+    assert outs[0][0] == [sk.randomize(sk.enc_raw(m), r) for m, r in zip(ms, rhos)]
