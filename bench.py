@@ -114,7 +114,7 @@ def main() -> None:
     ap.add_argument("--l", type=int, default=32)
     ap.add_argument("--pbits", type=int, default=2048)
     ap.add_argument("--rbits", type=int, default=400)
-    ap.add_argument("--fb-window", type=int, default=16, help="window of the fixed-base table for h (2^w rows of 288 B per window, HBM-resident)")
+    ap.add_argument("--fb-window", type=int, default=20, help="window of the fixed-base table for h (2^w rows of 288 B per window: 6 GB at w = 20, HBM-resident)")
     ap.add_argument("--no-crt", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0)
