@@ -180,6 +180,45 @@ struct Grp {
       r[1] += v >> W;
     }
   }
+  // Two products sharing one reduction: r = (a1 * b1 + a2 * b2 + init + q n) / R.  Three products per column and limb
+  // step: 3L * 2^58 < 2^64 holds for L <= 18 only (static_assert), which is where the pair arithmetic uses it.
+  __device__ __forceinline__ void mont2(uint32_t (&r)[L], const uint32_t* a1_lds, const uint32_t (&b1)[L], const uint32_t* a2_lds,
+                                        const uint32_t (&b2)[L], const uint32_t (&init)[L]) const {
+    uint64_t T[L];
+#pragma unroll
+    for (int i = 0; i < L; i++) T[i] = (uint64_t)init[i];
+#pragma unroll 1
+    for (int k = 0; k < G; k++) {
+#pragma unroll
+      for (int l = 0; l < L; l++) {
+        const uint32_t a1 = a1_lds[k * L + l], a2 = a2_lds[k * L + l];
+#pragma unroll
+        for (int c = 0; c < L; c++) T[(l + c) % L] += (uint64_t)a1 * b1[c];
+#pragma unroll
+        for (int c = 0; c < L; c++) T[(l + c) % L] += (uint64_t)a2 * b2[c];
+        uint32_t q = ((uint32_t)T[l] * n0inv) & LMASK;
+        q = bcast0<G>(q);
+#pragma unroll
+        for (int c = 0; c < L; c++) T[(l + c) % L] += (uint64_t)q * n[c];
+        const uint64_t t0 = T[l];
+        T[(l + 1) % L] += t0 >> W;
+        T[l] = (uint64_t)(from_above_raw((uint32_t)t0) & LMASK);
+      }
+    }
+    uint64_t c = 0;
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+      const uint64_t v = T[l] + c;
+      r[l] = (uint32_t)v & LMASK;
+      c = v >> W;
+    }
+    if constexpr (G > 1) {
+      const uint32_t clo = from_below((uint32_t)c), chi = from_below((uint32_t)(c >> 32));
+      const uint64_t v = (uint64_t)r[0] + (((uint64_t)chi << 32) | clo);
+      r[0] = (uint32_t)v & LMASK;
+      r[1] += (uint32_t)(v >> W);
+    }
+  }
   __device__ __forceinline__ void mul(uint32_t (&r)[L], const uint32_t* a_lds, const uint32_t (&b)[L]) const {
     uint32_t dummy[L];
     mont<0>(r, a_lds, b, dummy);
@@ -237,10 +276,16 @@ struct Grp {
     for (int l = 0; l < L; l++) q[l] = 0;
     mont<0, true, false, false>(t, y0_lds, x0, q);                   // t = (x0 y0 + q n) / R
     neg_quot_init(q);
-    mont<0, false, true, false>(x0, y1_lds, x0, q, nullptr, q);      // x0 <- (x0 y1 + R - q + ..) / R
-    mont<0, false, false, false>(x1, y0_lds, x1, q);                 // x1 <- (x1 y0 + ..) / R
+    if constexpr (L <= 18) {
+      mont2(x1, y1_lds, x0, y0_lds, x1, q);                          // x1 <- (x0 y1 + x1 y0 + R - q + q' n) / R, one reduction
 #pragma unroll
-    for (int l = 0; l < L; l++) { x1[l] += x0[l]; x0[l] = t[l]; }
+      for (int l = 0; l < L; l++) x0[l] = t[l];
+    } else {
+      mont<0, false, true, false>(x0, y1_lds, x0, q, nullptr, q);    // x0 <- (x0 y1 + R - q + ..) / R
+      mont<0, false, false, false>(x1, y0_lds, x1, q);               // x1 <- (x1 y0 + ..) / R
+#pragma unroll
+      for (int l = 0; l < L; l++) { x1[l] += x0[l]; x0[l] = t[l]; }
+    }
     pair_fix(x1);
   }
   // (x0, x1) <- (w0, w1) with  w0 + w1 n = (x0 + x1 n) / R  (mod n^2): leaves the pair form (w0, w1 < 2n + 1, lazy)

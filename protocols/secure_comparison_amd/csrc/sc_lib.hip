@@ -1113,7 +1113,7 @@ int sc_modexp_shared_sq(sc_ctx* ctx, int mod_m, int mod_m2, int exp, const uint3
     std::vector<VmOp> ops;
     uint32_t nsc = 2;
     double macs = 0;
-    const double S2 = (double)m.S * m.S, SQ = S2 + (double)m.G * m.L * (m.L + 1) / 2.0 + 2.0 * S2, MU = 6.0 * S2;
+    const double S2 = (double)m.S * m.S, SQ = S2 + (double)m.G * m.L * (m.L + 1) / 2.0 + 2.0 * S2, MU = 5.0 * S2;
     auto emit = [&](uint32_t opc, uint32_t w1 = 0, uint32_t w2 = 0, uint32_t w3 = 0) { ops.push_back(VmOp{opc, w1, w2, w3}); };
     auto touch = [&](uint32_t e) { nsc = std::max(nsc, 2 * e + 2); };
     // embed the operand: Horner over chunks of nwords words; constants: LDS 2,3 = pair(R^2), 4,5 = pair(B R)
