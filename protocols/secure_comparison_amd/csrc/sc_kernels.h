@@ -13,7 +13,7 @@ namespace sc {
 // the program and grid-strides over the batch.
 // ---------------------------------------------------------------------------------------------
 template <int G, int L, int WB>
-__global__ void __launch_bounds__(64, ((L > 18 || G == 16) ? 1 : SC_VM_WAVES)) k_vm(const VmArgs args) {
+__global__ void __launch_bounds__(64, ((L > 18 || (G == 16 && L > 14)) ? 1 : SC_VM_WAVES)) k_vm(const VmArgs args) {
   using GT = Grp<G, L, WB>;
   constexpr int S = GT::S, NG = GT::NG, SP = GT::SP, WP = GT::WP;
   __shared__ uint32_t s_a[NG * SP];            // per-group staging area for the LDS-side operand

@@ -103,7 +103,10 @@ struct Config { int G, L, W; };
 // ordered by capacity W*G*L; sc_mod_create takes the first one that fits.  A 28-bit-limb L = 37 family ((2,37), (4,37)) was
 // built and measured in round 1: it needs > 256 registers (one wave per SIMD plus AGPR copies) and came out 2-3 % slower
 // than (4,18) / (8,18), so it is not compiled in; the limb width stays a template parameter for such experiments.
-const Config kConfigs[] = {{1, 18, 29}, {2, 18, 29}, {2, 27, 29}, {4, 18, 29}, {4, 27, 29}, {8, 18, 29}, {8, 27, 29}, {16, 18, 29}};
+const Config kConfigs[] = {{1, 18, 29}, {2, 18, 29}, {2, 27, 29}, {4, 14, 29}, {4, 18, 29}, {4, 27, 29}, {8, 14, 29}, {8, 18, 29}, {8, 27, 29}, {16, 14, 29}, {16, 18, 29}};
+// configurations with a pair kernel (k_pvm): every L = 18 one, and (4,14) / (8,14) for the 1536 / 3072-bit sizes whose direct
+// configuration is L = 27 (the pair arithmetic needs the L <= 18 column bound)
+inline bool pair_capable(int G, int L, int W) { return W == 29 && (L == 18 || (L == 14 && (G == 4 || G == 8))); }
 
 struct Mod {
   int G = 0, L = 0, W = 29, S = 0, nwords = 0, nbits = 0;
@@ -144,6 +147,7 @@ struct sc_ctx {
   std::map<std::vector<uint32_t>, uint32_t*> nwords_cache;  // device copy of {n, (n-1)/2} for the plain-word kernels
   std::map<int, int> kred_cache;                            // mod -> constant id of 2^(32 nwords) (wide-operand reduction)
   std::map<std::pair<int, std::vector<uint32_t>>, int> const_by_value;  // (mod, residue) -> constant id
+  std::map<int, int> pair_twins;                            // mod -> context of the same modulus in a pair-capable configuration
   std::map<int, uint32_t*> pair_consts;                     // mod -> 4 limb arrays: pair(R^2), pair(B R) for the pair arithmetic
 };
 
@@ -331,16 +335,16 @@ int run_vm(sc_ctx* ctx, int mod, const Prog& p, const VmExt* exts, int next, uin
   int ci = 0;
 #define SC_CASE(GG, LL, WW) if (m.G == GG && m.L == LL && m.W == WW) rc = launch_vm_cfg<GG, LL, WW>(ctx, a, ci); ci++;
   SC_CASE(1, 18, 29) SC_CASE(2, 18, 29) SC_CASE(2, 27, 29) SC_CASE(4, 18, 29) SC_CASE(4, 27, 29) SC_CASE(8, 18, 29) SC_CASE(8, 27, 29)
-  SC_CASE(16, 18, 29)
+  SC_CASE(16, 18, 29) SC_CASE(4, 14, 29) SC_CASE(8, 14, 29) SC_CASE(16, 14, 29)
 #undef SC_CASE
   if (rc == SC_ERR_UNSUPPORTED) return fail(ctx, rc, "no kernel configuration for G=%d L=%d", m.G, m.L);
   return rc;
 }
 
-template <int G>
+template <int G, int L>
 int launch_pvm_cfg(sc_ctx* ctx, const VmArgs& a) {
-  constexpr int L = 18, NG = 64 / G;
-  const int key = 1000 + G;
+  constexpr int NG = 64 / G;
+  const int key = 1000 + 100 * L + G;
   auto it = ctx->occ_cache.find(key);
   int occ;
   if (it == ctx->occ_cache.end()) {
@@ -373,13 +377,17 @@ int run_pvm(sc_ctx* ctx, int mod, const Prog& p, const VmExt* exts, int next, ui
   a.nops = p.nops; a.nconst_extra = p.nconst; a.nscratch = p.nscratch;
   for (int i = 0; i < next; i++) a.ext[i] = exts[i];
   ctx->mac_counter += (double)count * p.muls_per_item;   // pair programs carry their exact multiply-add count here
-  if (m.L != 18 || m.W != 29) return fail(ctx, SC_ERR_UNSUPPORTED, "pair arithmetic needs an L = 18 configuration");
-  switch (m.G) {
-    case 1: return launch_pvm_cfg<1>(ctx, a);
-    case 2: return launch_pvm_cfg<2>(ctx, a);
-    case 4: return launch_pvm_cfg<4>(ctx, a);
-    case 8: return launch_pvm_cfg<8>(ctx, a);
-    case 16: return launch_pvm_cfg<16>(ctx, a);
+  if (!pair_capable(m.G, m.L, m.W)) return fail(ctx, SC_ERR_UNSUPPORTED, "no pair kernel for G=%d L=%d", m.G, m.L);
+  if (m.L == 18) switch (m.G) {
+    case 1: return launch_pvm_cfg<1, 18>(ctx, a);
+    case 2: return launch_pvm_cfg<2, 18>(ctx, a);
+    case 4: return launch_pvm_cfg<4, 18>(ctx, a);
+    case 8: return launch_pvm_cfg<8, 18>(ctx, a);
+    case 16: return launch_pvm_cfg<16, 18>(ctx, a);
+  }
+  if (m.L == 14) switch (m.G) {
+    case 4: return launch_pvm_cfg<4, 14>(ctx, a);
+    case 8: return launch_pvm_cfg<8, 14>(ctx, a);
   }
   return fail(ctx, SC_ERR_UNSUPPORTED, "no pair kernel for G=%d", m.G);
 }
@@ -494,7 +502,14 @@ int sc_memcpy_d2h(sc_ctx* ctx, void* hptr, const void* dptr, size_t bytes) {
   return SC_OK;
 }
 
+static int create_mod(sc_ctx* ctx, const uint32_t* n_hptr, int nwords, bool for_pairs, int* out_mod);
+
 int sc_mod_create(sc_ctx* ctx, const uint32_t* n_hptr, int nwords, int* out_mod) {
+  return create_mod(ctx, n_hptr, nwords, false, out_mod);
+}
+
+// for_pairs: take the first configuration that has a pair kernel (used for the internal twin context of sc_modexp_shared_sq)
+static int create_mod(sc_ctx* ctx, const uint32_t* n_hptr, int nwords, bool for_pairs, int* out_mod) {
   if (!ctx || !n_hptr || nwords <= 0 || !out_mod) return fail(ctx, SC_ERR_ARG, "sc_mod_create: bad argument");
   Mod m;
   m.n.assign(n_hptr, n_hptr + nwords);
@@ -507,6 +522,7 @@ int sc_mod_create(sc_ctx* ctx, const uint32_t* n_hptr, int nwords, int* out_mod)
   };
   for (int pass = 0; pass < 2 && !m.G; pass++)
     for (const Config& c : kConfigs) {
+      if (for_pairs && !pair_capable(c.G, c.L, c.W)) continue;
       if (fits(c, pass == 0)) { m.G = c.G; m.L = c.L; m.W = c.W; break; }
     }
   if (!m.G) return fail(ctx, SC_ERR_UNSUPPORTED, "sc_mod_create: %d-bit modulus exceeds the largest configuration", m.nbits);
@@ -1081,9 +1097,25 @@ static int get_pair_consts(sc_ctx* ctx, int mod, uint32_t** out) {
   return SC_OK;
 }
 
+// the context the pair kernel runs in for modulus `mod`: itself when its configuration has a pair kernel, otherwise a twin
+// context of the same modulus in a pair-capable configuration (created on first use); -1 if no configuration fits
+static int pair_twin(sc_ctx* ctx, int mod) {
+  {
+    const Mod& m = ctx->mods[mod];
+    if (pair_capable(m.G, m.L, m.W)) return mod;
+  }
+  auto it = ctx->pair_twins.find(mod);
+  if (it != ctx->pair_twins.end()) return it->second;
+  const Big n = ctx->mods[mod].n;
+  int twin = -1;
+  if (create_mod(ctx, n.data(), (int)n.size(), true, &twin) != SC_OK) twin = -1;
+  ctx->pair_twins[mod] = twin;
+  return twin;
+}
+
 int sc_mod_supports_sq(sc_ctx* ctx, int mod) {
   if (!valid_mod(ctx, mod)) return SC_ERR_ARG;
-  return (ctx->mods[mod].L == 18 && ctx->mods[mod].W == 29) ? 1 : 0;
+  return pair_twin(ctx, mod) >= 0 ? 1 : 0;
 }
 
 int sc_modexp_shared_sq(sc_ctx* ctx, int mod_m, int mod_m2, int exp, const uint32_t* x, int x_words, const uint32_t* mul_into,
@@ -1091,9 +1123,10 @@ int sc_modexp_shared_sq(sc_ctx* ctx, int mod_m, int mod_m2, int exp, const uint3
   if (ctx && count == 0) return SC_OK;
   if (!valid_mod(ctx, mod_m) || !valid_mod(ctx, mod_m2) || exp < 0 || exp >= (int)ctx->exps.size() || !x || !out || x_words <= 0)
     return fail(ctx, SC_ERR_ARG, "sc_modexp_shared_sq: bad argument");
+  mod_m = pair_twin(ctx, mod_m);
+  if (mod_m < 0) return fail(ctx, SC_ERR_UNSUPPORTED, "sc_modexp_shared_sq: no pair configuration fits this modulus");
   const Mod& m = ctx->mods[mod_m];
   const Mod& m2 = ctx->mods[mod_m2];
-  if (m.L != 18 || m.W != 29) return fail(ctx, SC_ERR_UNSUPPORTED, "sc_modexp_shared_sq: modulus needs an L = 18 configuration");
   {
     Big sq = big_mul(m.n, m.n);
     sq.resize(std::max(sq.size(), m2.n.size()), 0);

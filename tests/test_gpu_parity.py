@@ -389,11 +389,11 @@ def test_batched_interactive_protocol_on_gpu(engine, keys):
                 assert scheme._batch_pool.shape[0] == 0
 
 
-@pytest.mark.parametrize("bits", [512, 1024, 1536, 2048, 3072, 4096, 6144, 8192])
+@pytest.mark.parametrize("bits", [512, 1024, 1536, 1600, 2048, 3072, 3200, 4096, 6144, 6400, 8192])
 def test_worst_case_limbs(engine, bits):
     """Moduli and operands whose 29-bit limbs are all ones (n = 2^bits - c, a = n - 1, n - 2, 2^k - 1): the largest column
-    sums the lazy 64-bit accumulators can see, in every kernel configuration, through products, squarings and the
-    wide-operand reduction."""
+    sums the lazy 64-bit accumulators can see, in every kernel configuration (1600 / 3200 / 6400 bits select the L = 14
+    family, 1536 / 3072 / 6144 the L = 27 one), through products, squarings and the wide-operand reduction."""
     n = (1 << bits) - 1
     while n % 3 == 0 or n % 5 == 0 or n % 2 == 0:
         n -= 2
@@ -530,10 +530,11 @@ def test_config3_full_size_properties(engine, keys):
     assert bool((bob_p.decrypt_raw_batch(alice_p.randomize_batch(alice_p.encrypt_raw_batch(m), draws.rho_z)) == m).all().item())
 
 
-@pytest.mark.parametrize("bits", [256, 512, 1024, 2048])
+@pytest.mark.parametrize("bits", [256, 512, 1024, 1536, 2048, 3072])
 def test_pair_arithmetic_modexp(engine, bits):
     """sc_modexp_shared_sq (x^e mod m^2 with Montgomery products modulo m only) against Python pow: operands of 1, 2 and 4
-    chunks (wider than m^2 included), edge operands 0, 1, m, m - 1, m^2 - 1, exponents 1, 2, 3, m, m - 1 and random, mul_into."""
+    chunks (wider than m^2 included), edge operands 0, 1, m, m - 1, m^2 - 1, exponents 1, 2, 3, m, m - 1 and random, mul_into.
+    1536 and 3072 bits run the pair kernel in an internal twin context (L = 14) of a modulus whose own configuration is L = 27."""
     rng = random.Random(bits)
     m = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
     mm, mm2 = engine.modulus(m), engine.modulus(m * m, 2 * ((bits + 31) // 32))
