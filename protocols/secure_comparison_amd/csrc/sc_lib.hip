@@ -879,13 +879,17 @@ static int modinv_rec(sc_ctx* ctx, int mod, const uint32_t* x, uint32_t* out, ui
       if (st[i] != 1) { if (bad) *bad = (int64_t)i; return fail(ctx, SC_ERR_NOT_INVERTIBLE, "element %llu is not invertible", (unsigned long long)i); }
     return SC_OK;
   }
-  const uint32_t K = 24;
+  // Chunk length: a chunk is one sequential chain of 3 (K - 1) products, so the tree's latency is the sum of the chunk lengths
+  // over its levels while its work (3 products per element) does not depend on K.  Take the shortest chunks that still fill
+  // every resident group slot of the chip at this level (large batches: up to 24), and never fewer than 4 (fewer, wider levels).
+  const uint64_t resident_groups = (uint64_t)ctx->num_cu * 8 * (64 / m.G);
+  const uint32_t K = (uint32_t)std::min<uint64_t>(24, std::max<uint64_t>(4, (count + resident_groups - 1) / resident_groups));
   const uint64_t C = (count + K - 1) / K;
   uint32_t *d_P = nullptr, *d_tot = nullptr, *d_totinv = nullptr;
   { int rc0 = tmp_buf(ctx, TMP_INV_BASE + 2 * depth, (size_t)K * C * m.S * 4, (void**)&d_P); if (rc0) return rc0; }
   { int rc0 = tmp_buf(ctx, TMP_INV_BASE + 2 * depth + 1, (size_t)C * m.nwords * 4 * 2, (void**)&d_tot); if (rc0) return rc0; }
   d_totinv = d_tot + (size_t)C * m.nwords;
-  std::string k1 = "inv1:" + std::to_string(mod), k2 = "inv2:" + std::to_string(mod);
+  std::string k1 = "inv1:" + std::to_string(mod) + ":" + std::to_string(K), k2 = "inv2:" + std::to_string(mod) + ":" + std::to_string(K);
   auto it1 = ctx->progs.find(k1);
   if (it1 == ctx->progs.end()) {
     Builder bd;

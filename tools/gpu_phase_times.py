@@ -19,11 +19,12 @@ bob_p = Paillier(p * q, p, q); alice_p = bob_p.public_copy()
 bob_d = DGK(int(dj["p"], 16) * int(dj["q"], 16), int(dj["g"], 16), int(dj["h"], 16), int(dj["u"], 16), dj["t"], int(dj["p"], 16), int(dj["q"], 16), int(dj["v_p"], 16), int(dj["v_q"], 16), randomizer_bits=rbits, fixed_base_window=fbw)
 alice_d = bob_d.public_copy(); _ = bob_d.fb_h, alice_d.fb_h
 x, y, x_enc, y_enc, draws = bench.synth_inputs(eng, l, alice_p, bob_p, bob_d, B, rbits, 0)
-times = {}
+times, macs = {}, {}
 def timed(name, fn):
-    torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize(); times[name] = times.get(name, 0) + (time.perf_counter() - t0) * 1e3; return r
+    torch.cuda.synchronize(); eng.mac_counter(reset=True); t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize()
+    times[name] = times.get(name, 0) + (time.perf_counter() - t0) * 1e3; macs[name] = macs.get(name, 0) + eng.mac_counter(); return r
 for it in range(1 if pbits > 2048 else 2):
-    times.clear()
+    times.clear(); macs.clear()
     z_enc, a_plain = timed("A step1 (inv x, enc, 2 mul)", lambda: Initiator.step_1_batch(x_enc, y_enc, l, alice_p, draws.r))
     z_enc = timed("A randomize z (rho^N mod N^2)", lambda: alice_p.randomize_batch(z_enc, draws.rho_z))
     b_plain = timed("B step2 decrypt (CRT)", lambda: KeyHolder.step_2_batch(z_enc, l, bob_p))
@@ -43,5 +44,5 @@ for it in range(1 if pbits > 2048 else 2):
     blta = timed("A step6", lambda: Initiator.step_6_batch(draws.delta_a, db, alice_p))
     res = timed("A step7", lambda: Initiator.step_7_batch(z1, z2, a_plain, l, blta, alice_p))
 tot = sum(times.values())
-for k, v in times.items(): print(f"{k:40s} {v:8.1f} ms  {100*v/tot:5.1f}%")
+for k, v in times.items(): print(f"{k:40s} {v:8.1f} ms  {100*v/tot:5.1f}%  {macs[k]/v/1e9:6.2f} T limb-MAC/s executed")
 print(f"total {tot:.1f} ms -> {B/tot*1e3:.0f} cmp/s")
