@@ -269,14 +269,16 @@ def main() -> None:
         if world == 1:
             host_in = [t.cpu().pin_memory() for t in (x_enc, y_enc, draws.r, draws.delta_a, draws.rhos, draws.rho_z, draws.r_bob_dgk,
                                                       draws.r_alice_dgk, draws.rho_zeta_1, draws.rho_zeta_2, draws.rho_delta_b)]
-            torch.cuda.synchronize()
-            tp = time.perf_counter()
-            dv = [t.to(eng.device, non_blocking=True) for t in host_in]
-            d2 = BatchDraws(r=dv[2], delta_a=dv[3], rhos=dv[4], permutation=None, rho_z=dv[5], r_bob_dgk=dv[6], r_alice_dgk=dv[7],
-                            rho_zeta_1=dv[8], rho_zeta_2=dv[9], rho_delta_b=dv[10])
-            r2 = secure_comparison_batch(dv[0], dv[1], l, alice_p, alice_d, bob_p, bob_d, d2, randomize=True).cpu()
-            torch.cuda.synchronize()
-            pcie_s = time.perf_counter() - tp
+            for _ in range(2):                                # the first pass pays for the allocator's first-time hipMallocs
+                torch.cuda.synchronize()
+                tp = time.perf_counter()
+                dv = [t.to(eng.device, non_blocking=True) for t in host_in]
+                d2 = BatchDraws(r=dv[2], delta_a=dv[3], rhos=dv[4], permutation=None, rho_z=dv[5], r_bob_dgk=dv[6], r_alice_dgk=dv[7],
+                                rho_zeta_1=dv[8], rho_zeta_2=dv[9], rho_delta_b=dv[10])
+                r2 = secure_comparison_batch(dv[0], dv[1], l, alice_p, alice_d, bob_p, bob_d, d2, randomize=True).cpu()
+                torch.cuda.synchronize()
+                pcie_s = time.perf_counter() - tp
+                del dv, d2
             out["pcie_inclusive"] = {"value": B / pcie_s, "unit": "comparisons/s", "host_bytes_per_comparison":
                                      sum(t.numel() * t.element_size() for t in host_in) / B + r2.shape[-1] * 4}
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N = 1 only

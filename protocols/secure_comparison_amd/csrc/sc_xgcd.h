@@ -77,6 +77,25 @@ struct MW {
     return __ballot(o != 0) == 0;
   }
   static __device__ __forceinline__ bool odd(const uint32_t (&x)[WPL]) { return (__builtin_amdgcn_readfirstlane(x[0]) & 1u) != 0; }
+  // x = (x + m * n) / 2^32 with m = -x * n^-1 mod 2^32 (one word-level Montgomery step = 32 modular halvings at once);
+  // needs one spare word above n (x + m n < 2^32 n + n)
+  static __device__ __forceinline__ void halve32(uint32_t (&x)[WPL], const uint32_t (&n)[WPL], uint32_t n0inv) {
+    const uint32_t m = __builtin_amdgcn_readfirstlane(x[0]) * n0inv;
+    uint32_t lo[WPL], hi[WPL];
+#pragma unroll
+    for (int k = 0; k < WPL; k++) { lo[k] = n[k] * m; hi[k] = __umulhi(n[k], m); }
+    add(x, lo, false, 0);                                   // word 0 becomes zero
+    // the high halves enter one word higher: lane i word 0 takes lane i-1's top high half (wave_shr:1, lane 0 reads 0)
+    const uint32_t dn = __builtin_amdgcn_update_dpp(0u, hi[WPL - 1], 0x138, 0xf, 0xf, true);
+    uint32_t hs[WPL];
+#pragma unroll
+    for (int k = 0; k < WPL; k++) hs[k] = (k > 0) ? hi[k - 1] : dn;
+    add(x, hs, false, 0);
+    // drop the zero word: lane i word k takes word k+1, the top word of a lane comes from lane i+1 (wave_shl:1, lane 63 reads 0)
+    const uint32_t up = __builtin_amdgcn_update_dpp(0u, x[0], 0x130, 0xf, 0xf, true);
+#pragma unroll
+    for (int k = 0; k < WPL; k++) x[k] = (k + 1 < WPL) ? x[k + 1] : up;
+  }
 };
 
 template <int WPL>
@@ -121,10 +140,20 @@ __global__ void __launch_bounds__(64) k_xgcd(const uint32_t* __restrict__ xin, u
   for (int k = 0; k < WPL; k++) x[k] = n[k];
   M::add(x, r, true, 1);
   if (M::cmp(x, n) >= 0) M::add(x, n, true, 1);
-  for (int t = 0; t < kk; t++) {
+  // x * 2^-kk mod n: whole words by word-level Montgomery steps, the remaining kk mod 32 bits by modular halving
+  uint32_t n0inv = 1;
+  {
+    const uint32_t n0 = __builtin_amdgcn_readfirstlane(n[0]);
+    for (int i = 0; i < 5; i++) n0inv *= 2u - n0 * n0inv;   // n^-1 mod 2^32 (Newton)
+    n0inv = 0u - n0inv;
+  }
+  int t = 0;
+  for (; t + 32 <= kk; t += 32) M::halve32(x, n, n0inv);
+  for (; t < kk; t++) {
     if (M::odd(x)) M::add(x, n, false, 0);
     M::shr1(x);
   }
+  if (M::cmp(x, n) >= 0) M::add(x, n, true, 1);
   if (ok) {
 #pragma unroll
     for (int k = 0; k < WPL; k++) {
