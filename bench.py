@@ -222,7 +222,7 @@ def main() -> None:
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_dominant_kernel_traffic.json")
         if os.path.exists(tpath) and B == 65536 and args.pbits == 2048 and l == 32 and not args.no_crt:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch_uncorrected")
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         out = {
             "metric": "secure comparisons/sec (l=%d, %d-bit keys)" % (l, args.pbits), "value": value, "unit": "comparisons/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -239,7 +239,7 @@ def main() -> None:
                                  "(pair arithmetic, symmetric squaring) show up as frac > 1; executed_* counts the 29-bit multiply-adds actually issued",
                          "achieved": alg_macs / launch_s / 1e12, "peak": peak / 1e12, "unit": "T MAC/s (32x32->64)",
                          "frac": alg_macs / launch_s / peak, "traffic": traffic,
-                         "traffic_note": "HBM bytes per launch, (FETCH_SIZE+WRITE_SIZE)*1024 from profiles/r01_pmc_summary.csv (same build, separate rocprofv3 --pmc passes; 4-8 B/lane accesses, FETCH_SIZE 2x correction not calibrated for them)",
+                         "traffic_note": "HBM bytes moved per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r01_pmc_summary.csv (separate rocprofv3 --pmc passes; gfx950 tallies each 128-B line request at 64 B, confirmed for this library's limb rows in profiles/r01_traffic_calibration.json)",
                          "launch_ms": launch_s * 1e3,
                          "algorithmic_macs_per_launch": alg_macs},
             "modexp_per_s": {"P": B / launch_s, "D": d_rate,

@@ -155,6 +155,12 @@ int sc_peak_probe(sc_ctx* ctx, double* out_mac_per_s);
 /* Number of Montgomery limb-products (v_mad_u64_u32 lane operations) issued by library calls since the
  * last reset -- counted on the host from the micro-programs, used for the roofline numerator. */
 int sc_mac_counter(sc_ctx* ctx, int reset, double* out_macs);
+/* Measurement aid (bench / profiles only, no reference counterpart): per item, write `entries` rows of the per-slot scratch
+ * table and read rows back `reads` times with the kernels' own limb-form access pattern, then store the last row read
+ * (= x) to out[count][nwords].  Known HBM bytes per item: entries * S * 4 written, reads * S * 4 read (S = *out_row_limbs),
+ * plus one operand in and out -- the calibration point for the FETCH_SIZE / WRITE_SIZE counters of this access pattern. */
+int sc_table_traffic_probe(sc_ctx* ctx, int mod, const uint32_t* x, uint32_t* out, uint64_t count, int entries, int reads,
+                           int* out_row_limbs);
 
 #ifdef __cplusplus
 }

@@ -1237,6 +1237,27 @@ int sc_peak_probe(sc_ctx* ctx, double* out_mac_per_s) {
   return SC_OK;
 }
 
+int sc_table_traffic_probe(sc_ctx* ctx, int mod, const uint32_t* x, uint32_t* out, uint64_t count, int entries, int reads,
+                           int* out_row_limbs) {
+  if (!valid_mod(ctx, mod) || !x || !out || entries < 1 || entries > 64 || reads < 1 || reads > 4096)
+    return fail(ctx, SC_ERR_ARG, "sc_table_traffic_probe: bad argument");
+  const Mod& m = ctx->mods[mod];
+  if (out_row_limbs) *out_row_limbs = m.S;
+  std::string key = "tprobe:" + std::to_string(mod) + ":" + std::to_string(entries) + ":" + std::to_string(reads);
+  auto it = ctx->progs.find(key);
+  if (it == ctx->progs.end()) {
+    Builder bd;
+    bd.loadw(0); bd.mul_const(0);                                   // x in Montgomery form
+    for (int e = 0; e < entries; e++) bd.stt((uint32_t)e);          // `entries` rows written
+    for (int r = 0; r < reads; r++) bd.loadt_tbl((uint32_t)((r * 7 + 3) % entries));   // `reads` rows read
+    bd.redc(); bd.storew(1); bd.end();
+    Prog p; int rc = finalize_prog(ctx, m, bd, &p); if (rc) return rc;
+    it = ctx->progs.emplace(key, p).first;
+  }
+  VmExt ex[2] = {mk_ext(x, m.nwords, m.nwords), mk_ext(out, m.nwords, m.nwords)};
+  return run_vm(ctx, mod, it->second, ex, 2, count);
+}
+
 int sc_mac_counter(sc_ctx* ctx, int reset, double* out_macs) {
   if (!ctx) return SC_ERR_ARG;
   if (out_macs) *out_macs = ctx->mac_counter;

@@ -300,6 +300,15 @@ class Engine:
         self._check(self.lib.sc_peak_probe(self.ctx, C.byref(v)))
         return v.value
 
+    def table_traffic_probe(self, mod: Modulus, x: torch.Tensor, entries: int, reads: int) -> tuple[torch.Tensor, int]:
+        """Measurement aid (sc_table_traffic_probe): returns (x again, limbs per table row)."""
+        count = x.shape[0]
+        out = self.empty(count, mod.nwords)
+        s = C.c_int()
+        self._sync_stream()
+        self._check(self.lib.sc_table_traffic_probe(self.ctx, mod.id, self._ptr(x), self._ptr(out), count, entries, reads, C.byref(s)))
+        return out, s.value
+
     def mac_counter(self, reset: bool = False) -> float:
         v = C.c_double()
         self._check(self.lib.sc_mac_counter(self.ctx, int(reset), C.byref(v)))
