@@ -28,11 +28,11 @@ __device__ __forceinline__ uint32_t bcast0(uint32_t v) {  // value of the group'
   if constexpr (G == 1) {
     return v;
   } else if constexpr (G == 2) {
-    return __builtin_amdgcn_mov_dpp(v, 0xA0, 0xf, 0xf, false);  // quad_perm:[0,0,2,2]
+    return __builtin_amdgcn_update_dpp(0u, v, 0xA0, 0xf, 0xf, true);  // quad_perm:[0,0,2,2]; bound_ctrl so that a following mask can fold in
   } else if constexpr (G == 4) {
-    return __builtin_amdgcn_mov_dpp(v, 0x00, 0xf, 0xf, false);  // quad_perm:[0,0,0,0]
+    return __builtin_amdgcn_update_dpp(0u, v, 0x00, 0xf, 0xf, true);  // quad_perm:[0,0,0,0]
   } else if constexpr (G == 16) {
-    return __builtin_amdgcn_mov_dpp(v, 0x150, 0xf, 0xf, false);  // row_newbcast:0
+    return __builtin_amdgcn_update_dpp(0u, v, 0x150, 0xf, 0xf, true);  // row_newbcast:0
   } else {
     static_assert(G == 8, "unsupported group size");
     // two DPP moves; a single ds_swizzle (LDS crossbar, no VALU slot) was measured 4 % slower: its latency sits on
@@ -65,6 +65,8 @@ struct Grp {
   uint32_t notTop, notBot;                              // 0 for the top / bottom lane of the group
   uint32_t n[L];                                        // modulus limbs of this lane
   uint32_t n0inv;                                       // -n^-1 mod 2^29
+  uint32_t lmask_v;                                     // LMASK held in a VGPR the optimiser cannot see through: lets the masks
+                                                        // that follow a DPP move fold into one v_and_b32_dpp (no literal allowed there)
 
   __device__ __forceinline__ void init(const uint32_t* __restrict__ n_limbs, uint32_t n0inv_) {
     lane = threadIdx.x & 63;
@@ -73,6 +75,9 @@ struct Grp {
     notTop = (j == G - 1) ? 0u : ~0u;
     notBot = (j == 0) ? 0u : ~0u;
     n0inv = n0inv_;
+    uint32_t m = LMASK;
+    asm volatile("" : "+v"(m));
+    lmask_v = m;
 #pragma unroll
     for (int l = 0; l < L; l++) n[l] = n_limbs[j * L + l];
   }
@@ -136,8 +141,7 @@ struct Grp {
 #pragma unroll
           for (int c = l + 1; c < L; c++) T[(l + c) % L] += (uint64_t)ai2 * b[c];
         }
-        uint32_t q = ((uint32_t)T[l] * n0inv) & LMASK;
-        q = bcast0<G>(q);
+        const uint32_t q = bcast0<G>((uint32_t)T[l] * n0inv) & lmask_v;   // broadcast first: the mask folds into the DPP op
         if constexpr (COLLECT) quot[l] = (j == k) ? q : quot[l];
 #pragma unroll
         for (int c = 0; c < L; c++) T[(l + c) % L] += (uint64_t)q * n[c];
@@ -146,7 +150,7 @@ struct Grp {
         // The low limb moves to the lane below and becomes its new top column.  No group-boundary mask is needed:
         // the bottom lane of the group above contributes exactly 0 (its column 0 was just made divisible by 2^29),
         // and the DPP row end reads 0 (bound_ctrl).
-        T[l] = (uint64_t)(from_above_raw((uint32_t)t0) & LMASK);  // mask after the move: folds into v_and_b32_dpp
+        T[l] = (uint64_t)(from_above_raw((uint32_t)t0) & lmask_v);  // mask after the move: folds into v_and_b32_dpp
       }
     }
     // one local carry pass + hand the lane carry to the next lane (result "almost normalised")
@@ -196,13 +200,12 @@ struct Grp {
         for (int c = 0; c < L; c++) T[(l + c) % L] += (uint64_t)a1 * b1[c];
 #pragma unroll
         for (int c = 0; c < L; c++) T[(l + c) % L] += (uint64_t)a2 * b2[c];
-        uint32_t q = ((uint32_t)T[l] * n0inv) & LMASK;
-        q = bcast0<G>(q);
+        const uint32_t q = bcast0<G>((uint32_t)T[l] * n0inv) & lmask_v;
 #pragma unroll
         for (int c = 0; c < L; c++) T[(l + c) % L] += (uint64_t)q * n[c];
         const uint64_t t0 = T[l];
         T[(l + 1) % L] += t0 >> W;
-        T[l] = (uint64_t)(from_above_raw((uint32_t)t0) & LMASK);
+        T[l] = (uint64_t)(from_above_raw((uint32_t)t0) & lmask_v);
       }
     }
     uint64_t c = 0;

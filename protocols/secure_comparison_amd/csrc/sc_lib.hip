@@ -161,7 +161,9 @@ int fail(sc_ctx* ctx, int code, const char* fmt, ...) {
 }
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(ctx, SC_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
 
+// every allocation selects the context's device first: the caller may have switched the thread's current device
 int dev_alloc(sc_ctx* ctx, size_t bytes, void** out) {
+  HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipMalloc(out, bytes ? bytes : 4));
   ctx->owned.push_back(*out);
   return SC_OK;
@@ -176,6 +178,7 @@ int ensure_scratch(sc_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->scratch_bytes) return SC_OK;
   if (ctx->scratch) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->scratch)); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
   size_t want = bytes + bytes / 4;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipMalloc((void**)&ctx->scratch, want));
   ctx->scratch_bytes = want;
   return SC_OK;
@@ -188,6 +191,7 @@ int tmp_buf(sc_ctx* ctx, int slot, size_t bytes, void** out) {
   if (e.second < bytes) {
     if (e.first) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(e.first)); e.first = nullptr; e.second = 0; }
     size_t want = bytes + bytes / 8 + 256;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMalloc(&e.first, want));
     e.second = want;
   }
@@ -487,7 +491,12 @@ int sc_ctx_set_stream(sc_ctx* ctx, void* hip_stream) { if (!ctx) return SC_ERR_A
 int sc_ctx_synchronize(sc_ctx* ctx) { if (!ctx) return SC_ERR_ARG; HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); return SC_OK; }
 const char* sc_last_error(sc_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
-int sc_malloc(sc_ctx* ctx, size_t bytes, void** out_dptr) { if (!ctx || !out_dptr) return SC_ERR_ARG; HIPCHK(ctx, hipMalloc(out_dptr, bytes ? bytes : 4)); return SC_OK; }
+int sc_malloc(sc_ctx* ctx, size_t bytes, void** out_dptr) {
+  if (!ctx || !out_dptr) return SC_ERR_ARG;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMalloc(out_dptr, bytes ? bytes : 4));
+  return SC_OK;
+}
 int sc_free(sc_ctx* ctx, void* dptr) { if (!ctx) return SC_ERR_ARG; HIPCHK(ctx, hipFree(dptr)); return SC_OK; }
 int sc_memcpy_h2d(sc_ctx* ctx, void* dptr, const void* hptr, size_t bytes) {
   if (!ctx) return SC_ERR_ARG;
