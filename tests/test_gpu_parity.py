@@ -436,6 +436,19 @@ def test_steps_6_7_fused_equals_separate(engine, keys):
     assert engine.download(sep) == expect and engine.download(fused) == expect
 
 
+def test_table_traffic_probe_is_identity(engine):
+    """sc_table_traffic_probe (the FETCH_SIZE / WRITE_SIZE calibration launch) writes and re-reads table rows and must hand
+    back its operand unchanged; it reports the row length in limbs (72 for a 2048-bit modulus in the (4,18) configuration)."""
+    rng = random.Random(77)
+    n = rng.getrandbits(2048) | (1 << 2047) | 1
+    mod = engine.modulus(n)
+    xs = [0, 1, n - 1] + [rng.randrange(n) for _ in range(30)]
+    out, row_limbs = engine.table_traffic_probe(mod, engine.upload(xs, mod.nwords), 8, 40)
+    assert engine.download(out) == xs and row_limbs == 72
+    with pytest.raises(ValueError):
+        engine.table_traffic_probe(mod, engine.upload(xs, mod.nwords), 0, 40)
+
+
 def test_c_abi_without_torch_buffers():
     """The boundary is a plain C ABI: drive it with ctypes only (sc_malloc / sc_memcpy_*), no torch tensor in sight."""
     import ctypes as C
