@@ -116,6 +116,7 @@ def main() -> None:
     ap.add_argument("--rbits", type=int, default=400)
     ap.add_argument("--fb-window", type=int, default=20, help="window of the fixed-base table for h (2^w rows of 288 B per window: 6 GB at w = 20, HBM-resident)")
     ap.add_argument("--no-crt", action="store_true")
+    ap.add_argument("--latency-mode", type=int, default=1, help="small-batch kernel policy (sc_ctx_set_latency_mode): 0 never, 1 automatic, 2 always")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0)
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (exercises the RCCL path)")
@@ -141,6 +142,7 @@ def main() -> None:
     dj = keys[dname]
     p, q = int(pj["p"], 16), int(pj["q"], 16)
     eng = default_engine()
+    eng.set_latency_mode(args.latency_mode)
     bob_p = Paillier(p * q, p, q, use_crt=not args.no_crt)
     alice_p = bob_p.public_copy()
     bob_d = DGK(int(dj["p"], 16) * int(dj["q"], 16), int(dj["g"], 16), int(dj["h"], 16), int(dj["u"], 16), dj["t"],

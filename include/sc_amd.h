@@ -44,6 +44,10 @@ int sc_ctx_set_stream(sc_ctx* ctx, void* hip_stream);   /* hipStream_t; NULL = d
 int sc_ctx_synchronize(sc_ctx* ctx);
 const char* sc_last_error(sc_ctx* ctx);
 int sc_abi_version(void);
+/* Small-batch policy.  A modulus in an L = 18 configuration can be worked on by twice the lanes with 9 limbs each (same limb
+ * arrays in memory): twice the waves, 1.8x shorter dependent chains, lower multiply-add density.  mode 0: never; 1 (default):
+ * when the L = 18 launch would leave at least half of the SIMDs without a wave; 2: whenever such a kernel exists (tests). */
+int sc_ctx_set_latency_mode(sc_ctx* ctx, int mode);
 
 /* device memory helpers for callers that do not bring their own allocator */
 int sc_malloc(sc_ctx* ctx, size_t bytes, void** out_dptr);

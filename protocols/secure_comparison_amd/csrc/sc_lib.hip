@@ -147,6 +147,7 @@ struct sc_ctx {
   std::map<std::vector<uint32_t>, uint32_t*> nwords_cache;  // device copy of {n, (n-1)/2} for the plain-word kernels
   std::map<int, int> kred_cache;                            // mod -> constant id of 2^(32 nwords) (wide-operand reduction)
   std::map<std::pair<int, std::vector<uint32_t>>, int> const_by_value;  // (mod, residue) -> constant id
+  int latency_mode = 1;                                     // sc_ctx_set_latency_mode: 0 never, 1 automatic, 2 whenever available
   std::map<int, int> pair_twins;                            // mod -> context of the same modulus in a pair-capable configuration
   std::map<int, uint32_t*> pair_consts;                     // mod -> 4 limb arrays: pair(R^2), pair(B R) for the pair arithmetic
 };
@@ -317,6 +318,18 @@ int launch_vm_cfg(sc_ctx* ctx, const VmArgs& a, int cfg_index) {
   return SC_OK;
 }
 
+// Small batches: an L = 18 configuration with count * G lanes fills only part of the chip, and the run time is the latency of
+// one wave's chain of products.  The same limb arrays (S = G L limbs, identical layout in memory) can be worked on by twice
+// the lanes with half the limbs each -- (2G, 9) -- which doubles the waves and shortens the chain by 1.8x; the multiply-add
+// density drops from 88 % to 78 % of the instruction stream, so this is used only while the L = 18 launch would leave at
+// least half of the SIMDs without a wave.
+inline bool use_latency_config(const sc_ctx* ctx, const Mod& m, uint64_t count) {
+  if (ctx->latency_mode == 0 || m.L != 18 || m.W != 29 || m.G > 8) return false;
+  if (ctx->latency_mode == 2) return true;
+  const uint64_t waves = (count + (64 / m.G) - 1) / (64 / m.G);
+  return waves <= (uint64_t)ctx->num_cu * 2;
+}
+
 int run_vm(sc_ctx* ctx, int mod, const Prog& p, const VmExt* exts, int next, uint64_t count, const uint32_t* fbt_rows = nullptr) {
   if (count == 0) return SC_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));  // the caller may have switched the current device since sc_ctx_create
@@ -333,15 +346,20 @@ int run_vm(sc_ctx* ctx, int mod, const Prog& p, const VmExt* exts, int next, uin
   a.nconst_extra = p.nconst;
   a.nscratch = p.nscratch;
   for (int i = 0; i < next; i++) a.ext[i] = exts[i];
+  // multiply-adds issued per item: a product or a reduction pass is S^2 (S/G limb steps x L per lane x G lanes); the a*a part
+  // of a squaring is L(L+1)/2 per (lane, block) pair, G^2 pairs
+  const bool lat = use_latency_config(ctx, m, count);
+  const int G = lat ? 2 * m.G : m.G, L = lat ? 9 : m.L;
   ctx->mac_counter += (double)count * ((p.muls_per_item * 2.0 + p.redcs_per_item + p.sqrs_per_item) * (double)m.S * m.S +
-                                        p.sqrs_per_item * (double)m.G * m.L * (m.L + 1) / 2.0);
+                                        p.sqrs_per_item * (double)G * G * L * (L + 1) / 2.0);
   int rc = SC_ERR_UNSUPPORTED;
   int ci = 0;
-#define SC_CASE(GG, LL, WW) if (m.G == GG && m.L == LL && m.W == WW) rc = launch_vm_cfg<GG, LL, WW>(ctx, a, ci); ci++;
+#define SC_CASE(GG, LL, WW) if (G == GG && L == LL && m.W == WW) rc = launch_vm_cfg<GG, LL, WW>(ctx, a, ci); ci++;
   SC_CASE(1, 18, 29) SC_CASE(2, 18, 29) SC_CASE(2, 27, 29) SC_CASE(4, 18, 29) SC_CASE(4, 27, 29) SC_CASE(8, 18, 29) SC_CASE(8, 27, 29)
   SC_CASE(16, 18, 29) SC_CASE(4, 14, 29) SC_CASE(8, 14, 29) SC_CASE(16, 14, 29)
+  SC_CASE(2, 9, 29) SC_CASE(4, 9, 29) SC_CASE(8, 9, 29) SC_CASE(16, 9, 29)
 #undef SC_CASE
-  if (rc == SC_ERR_UNSUPPORTED) return fail(ctx, rc, "no kernel configuration for G=%d L=%d", m.G, m.L);
+  if (rc == SC_ERR_UNSUPPORTED) return fail(ctx, rc, "no kernel configuration for G=%d L=%d", G, L);
   return rc;
 }
 
@@ -382,6 +400,10 @@ int run_pvm(sc_ctx* ctx, int mod, const Prog& p, const VmExt* exts, int next, ui
   for (int i = 0; i < next; i++) a.ext[i] = exts[i];
   ctx->mac_counter += (double)count * p.muls_per_item;   // pair programs carry their exact multiply-add count here
   if (!pair_capable(m.G, m.L, m.W)) return fail(ctx, SC_ERR_UNSUPPORTED, "no pair kernel for G=%d L=%d", m.G, m.L);
+  if (use_latency_config(ctx, m, count) && (m.G == 2 || m.G == 4)) {
+    if (m.G == 2) return launch_pvm_cfg<4, 9>(ctx, a);
+    return launch_pvm_cfg<8, 9>(ctx, a);
+  }
   if (m.L == 18) switch (m.G) {
     case 1: return launch_pvm_cfg<1, 18>(ctx, a);
     case 2: return launch_pvm_cfg<2, 18>(ctx, a);
@@ -487,6 +509,11 @@ void sc_ctx_destroy(sc_ctx* ctx) {
   delete ctx;
 }
 
+int sc_ctx_set_latency_mode(sc_ctx* ctx, int mode) {
+  if (!ctx || mode < 0 || mode > 2) return SC_ERR_ARG;
+  ctx->latency_mode = mode;
+  return SC_OK;
+}
 int sc_ctx_set_stream(sc_ctx* ctx, void* hip_stream) { if (!ctx) return SC_ERR_ARG; ctx->stream = (hipStream_t)hip_stream; return SC_OK; }
 int sc_ctx_synchronize(sc_ctx* ctx) { if (!ctx) return SC_ERR_ARG; HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); return SC_OK; }
 const char* sc_last_error(sc_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -1159,7 +1186,7 @@ int sc_modexp_shared_sq(sc_ctx* ctx, int mod_m, int mod_m2, int exp, const uint3
     std::vector<VmOp> ops;
     uint32_t nsc = 2;
     double macs = 0;
-    const double S2 = (double)m.S * m.S, SQ = S2 + (double)m.G * m.L * (m.L + 1) / 2.0 + 2.0 * S2, MU = 5.0 * S2;
+    const double S2 = (double)m.S * m.S, SQ = S2 + (double)m.G * m.G * m.L * (m.L + 1) / 2.0 + 2.0 * S2, MU = 5.0 * S2;
     auto emit = [&](uint32_t opc, uint32_t w1 = 0, uint32_t w2 = 0, uint32_t w3 = 0) { ops.push_back(VmOp{opc, w1, w2, w3}); };
     auto touch = [&](uint32_t e) { nsc = std::max(nsc, 2 * e + 2); };
     // embed the operand: Horner over chunks of nwords words; constants: LDS 2,3 = pair(R^2), 4,5 = pair(B R)

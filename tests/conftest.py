@@ -40,4 +40,16 @@ def engine():
     """The HIP engine (GPU tests only).  No fallback: a missing library or GPU is a hard failure."""
     from protocols.secure_comparison_amd.schemes import default_engine
 
-    return default_engine()
+    eng = default_engine()
+    # the parity tests use small batches; keep them on each modulus's own kernel configuration.  The small-batch (2G, 9)
+    # kernels are exercised explicitly by the tests that take the `latency_engine` fixture.
+    eng.set_latency_mode(0)
+    return eng
+
+
+@pytest.fixture()
+def latency_engine(engine):
+    """The same engine with the small-batch kernel configurations forced on for the duration of one test."""
+    engine.set_latency_mode(2)
+    yield engine
+    engine.set_latency_mode(0)

@@ -589,3 +589,54 @@ def test_paillier_paths_agree(engine, keys):
             outs.append((engine.download(rnd), engine.download(p.decrypt_raw_batch(rnd))))
     assert all(o_ == outs[0] for o_ in outs) and outs[0][1] == ms
     assert outs[0][0] == [sk.randomize(sk.enc_raw(m), r) for m, r in zip(ms, rhos)]
+
+
+@pytest.mark.parametrize("bits", [512, 1024, 2048, 4000])
+def test_latency_configurations_primitives(latency_engine, bits):
+    """The small-batch kernels ((2G, 9) lanes x limbs on the limb arrays of an L = 18 modulus) give the same residues as Python
+    ints: products, shared and per-element exponentiation, inversion, wide operands, all-ones limbs, pair arithmetic."""
+    engine = latency_engine
+    rng = random.Random(9000 + bits)
+    for n in (rng.getrandbits(bits) | (1 << (bits - 1)) | 1, (1 << bits) - 1 - 2 * 44):
+        while n % 3 == 0 or n % 5 == 0:
+            n -= 2
+        mod = engine.modulus(n)
+        vals = [n - 1, n - 2, 1, 0, (1 << (bits - 1)) - 1] + [rng.randrange(n) for _ in range(28)]
+        t = engine.upload(vals, mod.nwords)
+        e = rng.getrandbits(300) | 1
+        assert engine.download(engine.modmul(mod, t, t)) == [v * v % n for v in vals]
+        assert engine.download(engine.modexp_shared(mod, t, e, mul_into=t)) == [pow(v, e, n) * v % n for v in vals]
+        ev = [rng.getrandbits(67) for _ in vals]
+        assert engine.download(engine.modexp_var(mod, t, engine.upload(ev, 3), 67)) == [pow(v, x, n) for v, x in zip(vals, ev)]
+        wide = [rng.getrandbits(2 * bits) for _ in range(9)]
+        assert engine.download(engine.modexp_shared(mod, engine.upload(wide, 2 * mod.nwords), 3)) == [pow(w, 3, n) for w in wide]
+        import math
+        inv_in = [v for v in vals if v and math.gcd(v, n) == 1] * 3       # 90+ elements: tree levels above the xgcd top
+        assert engine.download(engine.modinv(mod, engine.upload(inv_in, mod.nwords))) == [pow(v, -1, n) for v in inv_in]
+        if bits <= 2048:
+            mod2 = engine.modulus(n * n, 2 * mod.nwords)
+            assert engine.supports_sq(mod)
+            got = engine.download(engine.modexp_shared_sq(mod, mod2, t, n, mul_into=engine.upload([3] * len(vals), mod2.nwords)))
+            assert got == [pow(v, n, n * n) * 3 % (n * n) for v in vals]
+
+
+def test_latency_configurations_whole_comparison(latency_engine, keys):
+    """A batch of whole comparisons (2048-bit keys, l = 32, CRT key holder) through the small-batch kernels: bit-exact vs the oracle."""
+    engine = latency_engine
+    sk, dgk = oracle_paillier(keys, 2048), oracle_dgk(keys, "dgk_2048_l32")
+    l, B, rbits = 32, 24, 400
+    alice_p, alice_d, bob_p, bob_d = _schemes(engine, sk, dgk, rbits)
+    rng = random.Random(4242)
+    xs = [rng.randrange(1 << l) for _ in range(B)]
+    ys = [x if i % 4 == 0 else rng.randrange(1 << l) for i, x in enumerate(xs)]
+    drs = [o.draw(rng, l, sk, dgk, rbits) for _ in range(B)]
+    nw = alice_p.mod_n.nwords
+    x_enc = [sk.randomize(sk.enc_raw(x), 1 + rng.randrange(sk.n - 1)) for x in xs]
+    y_enc = [sk.randomize(sk.enc_raw(y), 1 + rng.randrange(sk.n - 1)) for y in ys]
+    draws = _draw_tensors(engine, drs, l, nw, (dgk.u.bit_length() + 31) // 32, (rbits + 31) // 32, engine.device)
+    from protocols.secure_comparison_amd.batch import secure_comparison_batch
+
+    res = secure_comparison_batch(engine.upload(x_enc, 2 * nw), engine.upload(y_enc, 2 * nw), l, alice_p, alice_d, bob_p, bob_d, draws, randomize=True)
+    expect = [o.compare(a, b, l, sk, dgk, dr, randomize=True) for a, b, dr in zip(x_enc, y_enc, drs)]
+    assert engine.download(res) == expect
+    assert [sk.dec_raw(c) for c in expect] == [int(x <= y) for x, y in zip(xs, ys)]
