@@ -101,7 +101,9 @@ struct Grp {
   // -------------------------------------------------------------------------------------------
   //   COLLECT (default: MODE 2): record the quotient digits.  INIT: the running sum starts at init[] instead of 0
   //   (MODE 1/2 always start at b).  Both are used by the pair arithmetic modulo n^2 further down.
-  template <int MODE, bool COLLECT = (MODE == 2), bool INIT = false, bool PRELOAD_A = true>
+  //   ADDN: the result gets n - 1 added inside the final carry pass (the pair arithmetic's correction for the start value
+  //   R - q, see pair_fix) instead of by a separate lazy addition and re-normalisation.
+  template <int MODE, bool COLLECT = (MODE == 2), bool INIT = false, bool PRELOAD_A = true, bool ADDN = false>
   __device__ __forceinline__ void mont(uint32_t (&r)[L], const uint32_t* a_lds, const uint32_t (&b)[L],
                                        uint32_t (&quot)[L], const uint32_t* a2_lds = nullptr,
                                        const uint32_t* init = nullptr) const {
@@ -154,10 +156,10 @@ struct Grp {
       }
     }
     // one local carry pass + hand the lane carry to the next lane (result "almost normalised")
-    uint64_t c = 0;
+    uint64_t c = ADDN ? (uint64_t)(n[0] - ((j == 0) ? 1u : 0u)) : 0ull;   // n is odd: limb 0 of lane 0 is >= 1
 #pragma unroll
     for (int l = 0; l < L; l++) {
-      const uint64_t v = T[l] + c;
+      const uint64_t v = T[l] + c + ((ADDN && l > 0) ? (uint64_t)n[l] : 0ull);
       r[l] = (uint32_t)v & LMASK;
       c = v >> W;
     }
@@ -186,6 +188,7 @@ struct Grp {
   }
   // Two products sharing one reduction: r = (a1 * b1 + a2 * b2 + init + q n) / R.  Three products per column and limb
   // step: 3L * 2^58 < 2^64 holds for L <= 18 only (static_assert), which is where the pair arithmetic uses it.
+  template <bool ADDN = false>
   __device__ __forceinline__ void mont2(uint32_t (&r)[L], const uint32_t* a1_lds, const uint32_t (&b1)[L], const uint32_t* a2_lds,
                                         const uint32_t (&b2)[L], const uint32_t (&init)[L]) const {
     uint64_t T[L];
@@ -208,10 +211,10 @@ struct Grp {
         T[l] = (uint64_t)(from_above_raw((uint32_t)t0) & lmask_v);
       }
     }
-    uint64_t c = 0;
+    uint64_t c = ADDN ? (uint64_t)(n[0] - ((j == 0) ? 1u : 0u)) : 0ull;
 #pragma unroll
     for (int l = 0; l < L; l++) {
-      const uint64_t v = T[l] + c;
+      const uint64_t v = T[l] + c + ((ADDN && l > 0) ? (uint64_t)n[l] : 0ull);
       r[l] = (uint32_t)v & LMASK;
       c = v >> W;
     }
@@ -269,8 +272,7 @@ struct Grp {
     for (int l = 0; l < L; l++) q[l] = 0;
     mont<3, true, false>(x0, a_lds, x0, q, a2_lds);                  // x0 <- t = (x0^2 + q n) / R
     neg_quot_init(q);
-    mont<0, false, true, false>(x1, a2_lds, x1, q, nullptr, q);      // x1 <- (2 x0 x1 + R - q + q' n) / R
-    pair_fix(x1);
+    mont<0, false, true, false, true>(x1, a2_lds, x1, q, nullptr, q);   // x1 <- (2 x0 x1 + R - q + q' n) / R + n - 1
   }
   // (x0, x1) <- (x0, x1) * (y0, y1) ;  y0_lds / y1_lds hold the second operand
   __device__ __forceinline__ void pair_mul(uint32_t (&x0)[L], uint32_t (&x1)[L], const uint32_t* y0_lds, const uint32_t* y1_lds) const {
@@ -280,7 +282,7 @@ struct Grp {
     mont<0, true, false, false>(t, y0_lds, x0, q);                   // t = (x0 y0 + q n) / R
     neg_quot_init(q);
     if constexpr (L <= 18) {
-      mont2(x1, y1_lds, x0, y0_lds, x1, q);                          // x1 <- (x0 y1 + x1 y0 + R - q + q' n) / R, one reduction
+      mont2<true>(x1, y1_lds, x0, y0_lds, x1, q);                    // x1 <- (x0 y1 + x1 y0 + R - q + q' n) / R + n - 1, one reduction
 #pragma unroll
       for (int l = 0; l < L; l++) x0[l] = t[l];
     } else {
@@ -288,8 +290,8 @@ struct Grp {
       mont<0, false, false, false>(x1, y0_lds, x1, q);               // x1 <- (x1 y0 + ..) / R
 #pragma unroll
       for (int l = 0; l < L; l++) { x1[l] += x0[l]; x0[l] = t[l]; }
+      pair_fix(x1);
     }
-    pair_fix(x1);
   }
   // (x0, x1) <- (w0, w1) with  w0 + w1 n = (x0 + x1 n) / R  (mod n^2): leaves the pair form (w0, w1 < 2n + 1, lazy)
   __device__ __forceinline__ void pair_redc(uint32_t (&x0)[L], uint32_t (&x1)[L]) const {
