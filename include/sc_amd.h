@@ -16,6 +16,9 @@
  *   - All functions return 0 on success or a negative sc_status; sc_last_error() gives the message.
  *   - Calls are asynchronous on the context's stream (sc_ctx_set_stream) unless stated otherwise.
  *   - No function falls back to host arithmetic: without a gfx950 device every call fails.
+ *   - A context belongs to one host thread at a time and orders all its work on one stream; its temporary device buffers are
+ *     reused from call to call, so a caller that changes the stream between calls must order the streams itself.  Use one
+ *     context per GPU (one process per GPU under torch.distributed).
  */
 #ifndef SC_AMD_H
 #define SC_AMD_H
