@@ -180,6 +180,9 @@ struct Grp {
       r[l] = v & LMASK;
       c = v >> W;
     }
+    // The group's top limb keeps its excess: a lazy sum may reach R and beyond (a raw chunk of 32 * nwords = 29 * S bits added
+    // to a residue, configurations (16,14) and (16,18)); the next product reads the limb as it is (< 2^32).
+    r[L - 1] += (c << W) & ~notTop;
     if constexpr (G > 1) {
       const uint32_t v = r[0] + from_below(c);
       r[0] = v & LMASK;

@@ -389,11 +389,13 @@ def test_batched_interactive_protocol_on_gpu(engine, keys):
                 assert scheme._batch_pool.shape[0] == 0
 
 
-@pytest.mark.parametrize("bits", [512, 1024, 1536, 1600, 2048, 3072, 3200, 4096, 6144, 6400, 8192])
+@pytest.mark.parametrize("bits", [512, 1024, 1536, 1600, 2048, 3072, 3200, 4096, 6144, 6400, 6470, 8192, 8330])
 def test_worst_case_limbs(engine, bits):
     """Moduli and operands whose 29-bit limbs are all ones (n = 2^bits - c, a = n - 1, n - 2, 2^k - 1): the largest column
     sums the lazy 64-bit accumulators can see, in every kernel configuration (1600 / 3200 / 6400 bits select the L = 14
-    family, 1536 / 3072 / 6144 the L = 27 one), through products, squarings and the wide-operand reduction."""
+    family, 1536 / 3072 / 6144 the L = 27 one), through products, squarings and the wide-operand reduction.  6470 and 8330 bits
+    are the two shapes whose residue arrays (203 / 261 words) fill all 29 * S bits of their configuration, so a raw chunk of the
+    wide operand can reach R - 1 and the lazy sum in the Horner reduction exceeds R (found by tools/gpu_fuzz.py)."""
     n = (1 << bits) - 1
     while n % 3 == 0 or n % 5 == 0 or n % 2 == 0:
         n -= 2
