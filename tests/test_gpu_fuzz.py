@@ -28,7 +28,8 @@ def protocol_round(engine, rng):
     from oracle import sc_oracle as o
     from protocols.secure_comparison_amd import keygen
     from protocols.secure_comparison_amd.batch import secure_comparison_batch
-    from test_gpu_parity import _draw_tensors, _schemes
+    from protocols.secure_comparison_amd import DGK, Paillier
+    from test_gpu_parity import _draw_tensors
 
     l = rng.choice([1, 3, 8, 16, 24])
     v_bits = rng.choice([24, 40, 64])
@@ -42,7 +43,10 @@ def protocol_round(engine, rng):
     rbits = int(2.5 * v_bits)
     use_crt = rng.random() < 0.7
     engine.set_latency_mode(rng.choice([0, 1, 2]))
-    alice_p, alice_d, bob_p, bob_d = _schemes(engine, sk, dgk, rbits, use_crt)
+    bob_p = Paillier(sk.n, sk.p, sk.q, engine=engine, use_crt=use_crt, use_pairs=rng.random() < 0.8)
+    bob_d = DGK(dgk.n, dgk.g, dgk.h, dgk.u, dgk.t, dgk.p, dgk.q, dgk.v_p, dgk.v_q, engine=engine, randomizer_bits=rbits,
+                fixed_base_window=rng.choice([1, 3, 8, 11]), use_crt=rng.random() < 0.7)
+    alice_p, alice_d = bob_p.public_copy(), bob_d.public_copy()
     B = rng.choice([1, 2, 7, 33])
     xs = [rng.randrange(1 << l) for _ in range(B)]
     ys = [xs[i] if i % 3 == 0 else rng.randrange(1 << l) for i in range(B)]

@@ -14,6 +14,9 @@ import time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 
 SIZES = [40, 64, 127, 256, 500, 514, 1024, 1030, 1536, 1550, 1600, 2048, 2060, 3072, 3100, 3200, 4096, 4150, 6144, 6200, 6400, 8192, 8300]
+# the largest moduli each configuration accepts (capacity 29 G L minus the 8 guard bits) and their neighbours
+CAPS = [522, 1044, 1566, 1624, 2088, 3132, 3248, 4176, 6264, 6496, 8352]
+SIZES += [c - d for c in CAPS for d in (8, 9, 31, 33)]
 
 
 def pattern(rng, bits):
