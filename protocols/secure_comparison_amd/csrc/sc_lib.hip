@@ -501,11 +501,12 @@ int sc_ctx_create(int device_id, sc_ctx** out_ctx) {
 
 void sc_ctx_destroy(sc_ctx* ctx) {
   if (!ctx) return;
-  hipSetDevice(ctx->device);
-  hipDeviceSynchronize();
-  for (void* p : ctx->owned) hipFree(p);
-  if (ctx->scratch) hipFree(ctx->scratch);
-  for (auto& kv : ctx->tmp) if (kv.second.first) hipFree(kv.second.first);
+  // teardown: errors are not reportable any more, results deliberately ignored
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  for (void* p : ctx->owned) (void)hipFree(p);
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  for (auto& kv : ctx->tmp) if (kv.second.first) (void)hipFree(kv.second.first);
   delete ctx;
 }
 
@@ -1268,7 +1269,7 @@ int sc_peak_probe(sc_ctx* ctx, double* out_mac_per_s) {
     double rate = (double)grid * 256 * (double)iters * 8 / (ms * 1e-3);
     if (rep > 0 && rate > best) best = rate;
   }
-  hipEventDestroy(e0); hipEventDestroy(e1); hipFree(d_out);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d_out);
   *out_mac_per_s = best;
   return SC_OK;
 }
