@@ -228,12 +228,13 @@ def main() -> None:
         out = {
             "metric": "secure comparisons/sec (l=%d, %d-bit keys)" % (l, args.pbits), "value": value, "unit": "comparisons/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (29-bit radix), u64 accumulate",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 (29-bit limbs held in u32, 32x32+64->64 multiply-accumulate)",
             "data": "synthetic",
             "config": {"workload": "batch %d comparisons per GPU, l=%d, %d-bit Paillier + %d-bit DGK (BASELINE configs[2])" % (B, l, args.pbits, args.pbits),
                        "batch_per_gpu": B, "l": l, "paillier_bits": args.pbits, "dgk_bits": args.pbits, "dgk_randomizer_bits": args.rbits,
                        "fixed_base_window": args.fb_window, "keyholder_crt": not args.no_crt, "parallelism": "shard%d" % world},
-            "roofline": {"bound": "valu-int (v_mad_u64_u32 issue; neither HBM nor MFMA bound, SURVEY 8(d))",
+            "roofline": {"bound": "valu-int",
+                         "bound_note": "v_mad_u64_u32 issue rate; neither HBM nor MFMA bounds this path (SURVEY 8(d)); the HBM view is in roofline_hbm",
                          "kernel": "k_pvm<4,18>: Paillier randomizer rho^N mod N^2 for B items, pair arithmetic modulo N (one launch) "
                                    "followed by the k_vm<8,18> launch that assembles w0 + w1 N and multiplies into the ciphertext",
                          "executed_achieved": launch_exec_macs / launch_s / 1e12, "executed_frac": launch_exec_macs / launch_s / peak,
