@@ -172,7 +172,10 @@ int dev_alloc(sc_ctx* ctx, size_t bytes, void** out) {
 int upload(sc_ctx* ctx, const void* h, size_t bytes, void** out) {
   int rc = dev_alloc(ctx, bytes, out);
   if (rc) return rc;
-  HIPCHK(ctx, hipMemcpy(*out, h, bytes, hipMemcpyHostToDevice));
+  // on the context's stream, then waited for: a plain hipMemcpy runs on the null stream, which does not order with the
+  // non-blocking streams a caller may hand in (torch side streams), and the source is a short-lived host buffer
+  HIPCHK(ctx, hipMemcpyAsync(*out, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return SC_OK;
 }
 int ensure_scratch(sc_ctx* ctx, size_t bytes) {
@@ -286,7 +289,8 @@ int finalize_prog(sc_ctx* ctx, const Mod& m, Builder& b, Prog* out) {
     rc = dev_alloc(ctx, (size_t)p.nconst * m.S * 4, (void**)&p.d_consts);
     if (rc) return rc;
     for (uint32_t i = 0; i < p.nconst; i++)
-      HIPCHK(ctx, hipMemcpy(p.d_consts + (size_t)i * m.S, ctx->consts[b.consts[i]].d_limbs, (size_t)m.S * 4, hipMemcpyDeviceToDevice));
+      HIPCHK(ctx, hipMemcpyAsync(p.d_consts + (size_t)i * m.S, ctx->consts[b.consts[i]].d_limbs, (size_t)m.S * 4,
+                                 hipMemcpyDeviceToDevice, ctx->stream));   // stream-ordered before the program's first launch
   }
   *out = p;
   return SC_OK;

@@ -642,3 +642,47 @@ def test_latency_configurations_whole_comparison(latency_engine, keys):
     expect = [o.compare(a, b, l, sk, dgk, dr, randomize=True) for a, b, dr in zip(x_enc, y_enc, drs)]
     assert engine.download(res) == expect
     assert [sk.dec_raw(c) for c in expect] == [int(x <= y) for x, y in zip(xs, ys)]
+
+
+def test_fresh_context_on_a_side_stream(keys):
+    """Everything created lazily (modulus contexts, constants, programs, fixed-base and CRT tables) while the caller's current
+    stream is a non-blocking side stream: set-up copies must be ordered on that stream, not on the null stream (regression:
+    a program's constants were copied on the null stream and could land after the first launch).  Two contexts on two streams
+    driven by two host threads, each bit-exact against the oracle."""
+    import threading
+
+    from protocols.secure_comparison_amd import DGK, Paillier
+    from protocols.secure_comparison_amd.batch import secure_comparison_batch
+    from protocols.secure_comparison_amd.engine import Engine
+
+    sk, dgk = oracle_paillier(keys, 1024), oracle_dgk(keys, "dgk_1024_l16")
+    l, B, rbits = 16, 48, 400
+    results, errors = {}, []
+
+    def worker(k):
+        try:
+            rng = random.Random(77 + k)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                eng = Engine()
+                bob_p = Paillier(sk.n, sk.p, sk.q, engine=eng)
+                bob_d = DGK(dgk.n, dgk.g, dgk.h, dgk.u, dgk.t, dgk.p, dgk.q, dgk.v_p, dgk.v_q, engine=eng, randomizer_bits=rbits)
+                alice_p, alice_d = bob_p.public_copy(), bob_d.public_copy()
+                xs = [rng.randrange(1 << l) for _ in range(B)]
+                ys = [rng.randrange(1 << l) for _ in range(B)]
+                drs = [o.draw(rng, l, sk, dgk, rbits) for _ in range(B)]
+                x_enc = [sk.randomize(sk.enc_raw(x), 1 + rng.randrange(sk.n - 1)) for x in xs]
+                y_enc = [sk.randomize(sk.enc_raw(y), 1 + rng.randrange(sk.n - 1)) for y in ys]
+                nw = bob_p.mod_n.nwords
+                draws = _draw_tensors(eng, drs, l, nw, (dgk.u.bit_length() + 31) // 32, (rbits + 31) // 32, eng.device)
+                got = eng.download(secure_comparison_batch(eng.upload(x_enc, 2 * nw), eng.upload(y_enc, 2 * nw), l, alice_p, alice_d,
+                                                           bob_p, bob_d, draws))
+                results[k] = (got, [o.compare(a, b, l, sk, dgk, d, True) for a, b, d in zip(x_enc, y_enc, drs)])
+        except Exception as exc:  # surfaced in the main thread below
+            errors.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+    for k in range(2):
+        assert results[k][0] == results[k][1]
