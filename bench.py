@@ -116,6 +116,7 @@ def main() -> None:
     ap.add_argument("--rbits", type=int, default=400)
     ap.add_argument("--fb-window", type=int, default=20, help="window of the fixed-base table for h (2^w rows of 288 B per window: 6 GB at w = 20, HBM-resident)")
     ap.add_argument("--no-crt", action="store_true")
+    ap.add_argument("--streams", type=int, default=2, help="concurrent shards per GPU (one library context, HIP stream and host thread each); 1 = a single stream")
     ap.add_argument("--latency-mode", type=int, default=1, help="small-batch kernel policy (sc_ctx_set_latency_mode): 0 never, 1 automatic, 2 always")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0)
@@ -152,8 +153,36 @@ def main() -> None:
     _ = bob_d.fb_h, alice_d.fb_h  # build the fixed-base tables (untimed set-up, like key generation)
     x, y, x_enc, y_enc, draws = synth_inputs(eng, l, alice_p, bob_p, bob_d, B, args.rbits, seed=rank)
 
+    # ---- concurrent shards (batch.ConcurrentShards): the batch is cut into `streams` contiguous shards once, outside the timed
+    # region (a caller that produces its inputs per shard pays nothing; cutting a resident batch is one ~1.5 GB device copy)
+    ns = max(1, min(args.streams, B))
+    runner, shard_inputs, engines = None, None, [eng]
+    if ns > 1:
+        from protocols.secure_comparison_amd.batch import ConcurrentShards, PartySet, split_draws
+        from protocols.secure_comparison_amd.distributed import shard_bounds
+        from protocols.secure_comparison_amd.engine import Engine
+
+        parties = [PartySet(alice_p, alice_d, bob_p, bob_d, torch.cuda.Stream())]
+        for _ in range(1, ns):
+            e_i = Engine()
+            e_i.set_latency_mode(args.latency_mode)
+            engines.append(e_i)
+            bp_i = Paillier(p * q, p, q, engine=e_i, use_crt=not args.no_crt)
+            bd_i = DGK(bob_d.public_key.n, bob_d.public_key.g, bob_d.public_key.h, bob_d.public_key.u, bob_d.public_key.t,
+                       int(dj["p"], 16), int(dj["q"], 16), int(dj["v_p"], 16), int(dj["v_q"], 16), engine=e_i,
+                       randomizer_bits=args.rbits, fixed_base_window=args.fb_window)
+            ad_i = bd_i.public_copy()
+            _ = bd_i.fb_h, ad_i.fb_h
+            parties.append(PartySet(bp_i.public_copy(), ad_i, bp_i, bd_i, torch.cuda.Stream()))
+        bounds = [shard_bounds(B, i, ns) for i in range(ns)]
+        shard_inputs = [(x_enc[a:b].contiguous(), y_enc[a:b].contiguous(), d) for (a, b), d in zip(bounds, split_draws(draws, bounds))]
+        runner = ConcurrentShards(parties)
+        torch.cuda.synchronize()
+
     def step():
-        return secure_comparison_batch(x_enc, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws, randomize=True)
+        if runner is None:
+            return secure_comparison_batch(x_enc, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws, randomize=True)
+        return torch.cat(runner.run(shard_inputs, l, randomize=True), dim=0)
 
     def gather(res):
         if dist is None:
@@ -172,7 +201,7 @@ def main() -> None:
         ok = bool(((dec[:, 0] == expect) & (dec[:, 1:] == 0).all(dim=1)).all().item())
         if not ok:
             raise SystemExit("bench.py: decrypted results differ from x <= y")
-    eng.mac_counter(reset=True)
+    [e_.mac_counter(reset=True) for e_ in engines]
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -187,7 +216,7 @@ def main() -> None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    executed_macs = eng.mac_counter()
+    executed_macs = sum(e_.mac_counter() for e_ in engines)
     value = world * B * args.steps / elapsed
 
     out = None
@@ -232,7 +261,8 @@ def main() -> None:
             "data": "synthetic",
             "config": {"workload": "batch %d comparisons per GPU, l=%d, %d-bit Paillier + %d-bit DGK (BASELINE configs[2])" % (B, l, args.pbits, args.pbits),
                        "batch_per_gpu": B, "l": l, "paillier_bits": args.pbits, "dgk_bits": args.pbits, "dgk_randomizer_bits": args.rbits,
-                       "fixed_base_window": args.fb_window, "keyholder_crt": not args.no_crt, "parallelism": "shard%d" % world},
+                       "fixed_base_window": args.fb_window, "keyholder_crt": not args.no_crt, "parallelism": "shard%d" % world,
+                       "streams_per_gpu": ns},
             "roofline": {"bound": "valu-int",
                          "bound_note": "v_mad_u64_u32 issue rate; neither HBM nor MFMA bounds this path (SURVEY 8(d)); the HBM view is in roofline_hbm",
                          "kernel": "k_pvm<4,18>: Paillier randomizer rho^N mod N^2 for B items, pair arithmetic modulo N (one launch) "

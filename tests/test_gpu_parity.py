@@ -686,3 +686,43 @@ def test_fresh_context_on_a_side_stream(keys):
     assert not errors, errors
     for k in range(2):
         assert results[k][0] == results[k][1]
+
+
+def test_concurrent_shards_equal_single_stream(engine, keys):
+    """batch.ConcurrentShards (two library contexts, two HIP streams, two host threads) returns the very residues of the
+    single-stream batch call, shard by shard, incl. a ragged split and a shuffle."""
+    from protocols.secure_comparison_amd import DGK, Paillier
+    from protocols.secure_comparison_amd.batch import ConcurrentShards, PartySet, secure_comparison_batch, split_draws
+    from protocols.secure_comparison_amd.distributed import shard_bounds
+    from protocols.secure_comparison_amd.engine import Engine
+
+    sk, dgk = oracle_paillier(keys, 1024), oracle_dgk(keys, "dgk_1024_l16")
+    l, B, rbits = 16, 37, 400
+    rng = random.Random(99)
+    alice_p, alice_d, bob_p, bob_d = _schemes(engine, sk, dgk, rbits)
+    xs = [rng.randrange(1 << l) for _ in range(B)]
+    ys = [rng.randrange(1 << l) for _ in range(B)]
+    drs = [o.draw(rng, l, sk, dgk, rbits) for _ in range(B)]
+    nw = bob_p.mod_n.nwords
+    x_enc = engine.upload([sk.randomize(sk.enc_raw(x), 1 + rng.randrange(sk.n - 1)) for x in xs], 2 * nw)
+    y_enc = engine.upload([sk.randomize(sk.enc_raw(y), 1 + rng.randrange(sk.n - 1)) for y in ys], 2 * nw)
+    draws = _draw_tensors(engine, drs, l, nw, (dgk.u.bit_length() + 31) // 32, (rbits + 31) // 32, engine.device)
+    single = secure_comparison_batch(x_enc, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws)
+
+    parties = [PartySet(alice_p, alice_d, bob_p, bob_d, torch.cuda.Stream())]
+    e2 = Engine()
+    bp2 = Paillier(sk.n, sk.p, sk.q, engine=e2)
+    bd2 = DGK(dgk.n, dgk.g, dgk.h, dgk.u, dgk.t, dgk.p, dgk.q, dgk.v_p, dgk.v_q, engine=e2, randomizer_bits=rbits)
+    parties.append(PartySet(bp2.public_copy(), bd2.public_copy(), bp2, bd2, torch.cuda.Stream()))
+    bounds = [shard_bounds(B, i, 2) for i in range(2)]
+    shards = [(x_enc[a:b].contiguous(), y_enc[a:b].contiguous(), d) for (a, b), d in zip(bounds, split_draws(draws, bounds))]
+    runner = ConcurrentShards(parties)
+    try:
+        for _ in range(3):
+            parts = runner.run(shards, l)
+            assert torch.equal(torch.cat(parts, dim=0), single)
+    finally:
+        runner.close()
+    assert [sk.dec_raw(c) for c in engine.download(single)] == [int(x <= y) for x, y in zip(xs, ys)]
+    with pytest.raises(ValueError):
+        ConcurrentShards([parties[0], parties[0]])
