@@ -116,7 +116,8 @@ def main() -> None:
     ap.add_argument("--rbits", type=int, default=400)
     ap.add_argument("--fb-window", type=int, default=20, help="window of the fixed-base table for h (2^w rows of 288 B per window: 6 GB at w = 20, HBM-resident)")
     ap.add_argument("--no-crt", action="store_true")
-    ap.add_argument("--streams", type=int, default=2, help="concurrent shards per GPU (one library context, HIP stream and host thread each); 1 = a single stream")
+    ap.add_argument("--streams", type=int, default=0, help="concurrent shards per GPU (one library context, HIP stream and host thread each); 1 = a single stream; "
+                    "0 = automatic: 2 from 65536 comparisons per GPU (smaller batches are bound by host-side launch work, which two threads only contend for)")
     ap.add_argument("--latency-mode", type=int, default=1, help="small-batch kernel policy (sc_ctx_set_latency_mode): 0 never, 1 automatic, 2 always")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0)
@@ -155,7 +156,7 @@ def main() -> None:
 
     # ---- concurrent shards (batch.ConcurrentShards): the batch is cut into `streams` contiguous shards once, outside the timed
     # region (a caller that produces its inputs per shard pays nothing; cutting a resident batch is one ~1.5 GB device copy)
-    ns = max(1, min(args.streams, B))
+    ns = max(1, min(args.streams, B)) if args.streams > 0 else (2 if B >= 65536 else 1)
     runner, shard_inputs, engines = None, None, [eng]
     if ns > 1:
         from protocols.secure_comparison_amd.batch import ConcurrentShards, PartySet, split_draws
