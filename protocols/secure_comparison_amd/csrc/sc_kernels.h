@@ -81,11 +81,24 @@ __global__ void __launch_bounds__(64, ((L > 18 || (G == 16 && L > 14)) ? 1 : SC_
 
       switch (opc) {
         case OP_MUL: {
-          __syncthreads();
           if (akind == AK_ACC) {
-            gp.stage(my_a, acc);
-            gp.stage_doubled(my_a2, acc);
-          } else if (akind == AK_EXTW) {
+            // imm = number of consecutive squarings (the host merges runs): the loop stays inside this case, so a run pays
+            // the fetch / decode of one micro-op
+#pragma unroll 1
+            for (uint32_t rep = (imm ? imm : 1); rep > 0; rep--) {
+              __syncthreads();
+              gp.stage(my_a, acc);
+              gp.stage_doubled(my_a2, acc);
+              __syncthreads();
+              uint32_t r[L];
+              gp.sqr(r, my_a, my_a2, acc);
+#pragma unroll
+              for (int l = 0; l < L; l++) acc[l] = r[l];
+            }
+            break;
+          }
+          __syncthreads();
+          if (akind == AK_EXTW) {
             const VmExt& e = args.ext[op.w1 & 0xf];
             const uint64_t flat = (uint64_t)op.w2 * args.count + idx;
             uint32_t t[L];
@@ -102,7 +115,7 @@ __global__ void __launch_bounds__(64, ((L > 18 || (G == 16 && L > 14)) ? 1 : SC_
           }
           __syncthreads();
           uint32_t r[L];
-          if (akind == AK_ACC) gp.sqr(r, a_ptr, my_a2, acc); else gp.mul(r, a_ptr, acc);
+          gp.mul(r, a_ptr, acc);
 #pragma unroll
           for (int l = 0; l < L; l++) acc[l] = r[l];
           break;

@@ -237,7 +237,15 @@ struct Builder {
     return 2 + (int)consts.size() - 1;
   }
   void mul_const(int lds_idx) { emit(OP_MUL, AK_CONST, 0, lds_idx); muls++; }
-  void sqr() { emit(OP_MUL, AK_ACC); sqrs++; }
+  void sqr() {   // consecutive squarings merge into one micro-op with a repeat count (imm, 16 bits)
+    sqrs++;
+    if (!ops.empty()) {
+      VmOp& last = ops.back();
+      const uint32_t imm = last.w0 >> 16;
+      if ((last.w0 & 0xffff) == (OP_MUL | (AK_ACC << 8)) && imm >= 1 && imm < 0xffff) { last.w0 += 1u << 16; return; }
+    }
+    emit(OP_MUL, AK_ACC, 1);
+  }
   void mul_tbl(uint32_t e) { touch(e); emit(OP_MUL, AK_TBL, 0, e); muls++; }
   void mul_tblsel(int extA, int bitA, int extB, int bitB, uint32_t e00, uint32_t e01, uint32_t e10, uint32_t e11) {
     touch(std::max(std::max(e00, e01), std::max(e10, e11)));
