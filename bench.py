@@ -1,11 +1,15 @@
 """bench.py -- secure comparisons / s on MI355X (BASELINE.json metric), one process per GPU.
 
-A "step" is one full batch of B independent secure comparisons (both parties' compute, every randomization,
-SURVEY 8(d)) on synthetic inputs already resident in HBM.  Default workload = BASELINE.json configs[2]:
-B = 65536, l = 32, 2048-bit Paillier + 2048-bit DGK on one GPU.  With N > 1 ranks each rank runs its own shard
-of B comparisons (weak scaling, no data-path collective) and the [[x<=y]] results are all-gathered over RCCL.
+A "step" is one full batch of B independent secure comparisons (both parties' compute, every randomization and the
+step-4i shuffle) on synthetic inputs already resident in HBM.  Default workload = BASELINE.json configs[2]:
+B = 65536, l = 32, 2048-bit Paillier + 2048-bit DGK on one GPU.  With N > 1 ranks each rank runs its own shard of B
+comparisons (weak scaling, no data-path collective) and the [[x<=y]] results are all-gathered over RCCL.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--l 32] [--pbits 2048]
+
+`--gpus N` with N > 1 and no launcher environment starts N rank processes itself (protocols.secure_comparison_amd.launcher:
+the parent never touches the GPU); under `python -m torch.distributed.run --nproc-per-node N` the launcher's WORLD_SIZE must
+equal N.  Either way a rank count that cannot be honoured is an error, not a one-rank run.
 """
 from __future__ import annotations
 
@@ -14,16 +18,11 @@ import json
 import os
 import subprocess
 import sys
+import tempfile
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-from protocols.secure_comparison_amd import DGK, Paillier  # noqa: E402
-from protocols.secure_comparison_amd.batch import BatchDraws, boot_pools, secure_comparison_batch  # noqa: E402
-from protocols.secure_comparison_amd.schemes import default_engine  # noqa: E402
 
 KEYS = os.path.join(ROOT, "tests", "golden", "keys.json")
 MAX_CLOCK_HZ = 2.4e9   # MI355X peak engine clock (MI355X_MICROARCH.md)
@@ -53,8 +52,13 @@ def algorithmic_bytes_per_comparison(l: int, pbits: int, dbits: int, rbits: int)
     return 2 * (2 * (l + 1) * ct_d) + 9 * ct_p + rand
 
 
-def synth_inputs(eng, l, alice_p, bob_p, bob_d, B, rbits, seed):
-    """Seeded synthetic batch, generated on the device (SURVEY 8(d) 'Synthetic inputs')."""
+def synth_inputs(eng, l, alice_p, bob_p, bob_d, B, rbits, seed, shuffle=False):
+    """Seeded synthetic batch, generated on the device (SURVEY 8(d) 'Synthetic inputs').  shuffle: also draw the step-4i
+    permutation of every comparison (SC/initiator.py:516, do_shuffle=True)."""
+    import torch
+
+    from protocols.secure_comparison_amd.batch import BatchDraws
+
     g = torch.Generator(device=eng.device)
     g.manual_seed(0xC0FFEE + seed)
     nw = alice_p.mod_n.nwords
@@ -103,10 +107,34 @@ def synth_inputs(eng, l, alice_p, bob_p, bob_d, B, rbits, seed):
         r_bob_dgk=rand_words(l + 1, B, er, top_bits_clear=32 * er - rbits),
         r_alice_dgk=rand_words(l + 1, B, er, top_bits_clear=32 * er - rbits),
         rho_zeta_1=below_n(B), rho_zeta_2=below_n(B), rho_delta_b=below_n(B))
+    if shuffle:   # drawn last so that the other inputs of a seed do not depend on the flag
+        draws.permutation = torch.argsort(torch.rand((B, l + 1), generator=g, device=dev, dtype=torch.float64), dim=1)
     return x, y, x_enc, y_enc, draws
 
 
-def main() -> None:
+def export_sample(path, eng, idx, l, x_enc, y_enc, draws, result):
+    """Rows `idx` of the resident batch (inputs, every random draw, and the GPU's results) as hex integers for the CPU
+    baseline leg: the oracle then runs THE SAME comparisons and its results are compared with the GPU's bit for bit."""
+    import torch
+
+    it = torch.tensor(idx, device=eng.device)
+    rows = lambda t: [hex(v) for v in eng.download(t[it])]                                   # noqa: E731
+    planes = lambda t: [[hex(v) for v in eng.download(t[:, i])] for i in idx]                # noqa: E731
+    perm = None if draws.permutation is None else draws.permutation[it].tolist()
+    r_alice = planes(draws.r_alice_dgk)
+    if perm is not None:
+        # the library randomizes c_j with r_alice[j] before the shuffle; the oracle randomizes output k = c_{perm[k]} after it
+        r_alice = [[row[src] for src in pm] for row, pm in zip(r_alice, perm)]
+    M = (1 << 64) - 1
+    doc = {"l": l, "x_enc": rows(x_enc), "y_enc": rows(y_enc), "r": rows(draws.r),
+           "delta_a": [int(v) & M for v in draws.delta_a[it].tolist()], "rhos": planes(draws.rhos), "perm": perm,
+           "rho_z": rows(draws.rho_z), "r_bob": planes(draws.r_bob_dgk), "r_alice": r_alice, "rho_zeta_1": rows(draws.rho_zeta_1),
+           "rho_zeta_2": rows(draws.rho_zeta_2), "rho_delta_b": rows(draws.rho_delta_b), "gpu_result": rows(result)}
+    with open(path, "w") as f:
+        json.dump(doc, f)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -114,20 +142,43 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=65536, help="comparisons per GPU per step")
     ap.add_argument("--l", type=int, default=32)
     ap.add_argument("--pbits", type=int, default=2048)
+    ap.add_argument("--dgk", default="", help="DGK key fixture (tests/golden/keys.json); default dgk_<pbits>_l<l>")
     ap.add_argument("--rbits", type=int, default=400)
     ap.add_argument("--fb-window", type=int, default=20, help="window of the fixed-base table for h (2^w rows of 288 B per window: 6 GB at w = 20, HBM-resident)")
     ap.add_argument("--no-crt", action="store_true")
+    ap.add_argument("--no-shuffle", action="store_true", help="leave the step-4i permutation out (do_shuffle=False)")
     ap.add_argument("--streams", type=int, default=0, help="concurrent shards per GPU (one library context, HIP stream and host thread each); 1 = a single stream; "
-                    "0 = automatic: 2 from 65536 comparisons per GPU (smaller batches are bound by host-side launch work, which two threads only contend for)")
+                    "0 = automatic: 2 from 65536 comparisons per GPU")
     ap.add_argument("--latency-mode", type=int, default=1, help="small-batch kernel policy (sc_ctx_set_latency_mode): 0 never, 1 automatic, 2 always")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0)
+    ap.add_argument("--no-extras", action="store_true", help="skip the informational legs (window sensitivity, online phase, PCIe-inclusive)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (exercises the RCCL path)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+def main() -> None:
+    args = parse_args()
+    from protocols.secure_comparison_amd import launcher
+
+    # ---- ranks: start them ourselves, or check the ones a launcher started.  Nothing above this line touches the GPU.
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and launcher.rank_env() is None:
+        sys.exit(launcher.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    rank, local_rank, world = launcher.expect_world(args.gpus)
+
+    import torch
+
+    from protocols.secure_comparison_amd import DGK, Paillier
+    from protocols.secure_comparison_amd.batch import (BatchDraws, ConcurrentShards, PartySet, boot_pools, secure_comparison_batch,
+                                                       split_draws)
+    from protocols.secure_comparison_amd.distributed import shard_bounds
+    from protocols.secure_comparison_amd.engine import Engine
+    from protocols.secure_comparison_amd.schemes import default_engine
+
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but this node shows {torch.cuda.device_count()} GPU(s) (no CPU fallback)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -141,50 +192,59 @@ def main() -> None:
     keys = json.load(open(KEYS))
     l, B = args.l, args.batch
     pj = keys[f"paillier_{args.pbits}"]
-    dname = f"dgk_{args.pbits}_l{l}"
+    dname = args.dgk or f"dgk_{args.pbits}_l{l}"
     dj = keys[dname]
+    dbits = (int(dj["p"], 16) * int(dj["q"], 16)).bit_length()
     p, q = int(pj["p"], 16), int(pj["q"], 16)
+    H = lambda name: int(dj[name], 16)  # noqa: E731
+    use_crt = not args.no_crt
     eng = default_engine()
-    eng.set_latency_mode(args.latency_mode)
-    bob_p = Paillier(p * q, p, q, use_crt=not args.no_crt)
-    alice_p = bob_p.public_copy()
-    bob_d = DGK(int(dj["p"], 16) * int(dj["q"], 16), int(dj["g"], 16), int(dj["h"], 16), int(dj["u"], 16), dj["t"],
-                int(dj["p"], 16), int(dj["q"], 16), int(dj["v_p"], 16), int(dj["v_q"], 16), randomizer_bits=args.rbits,
-                fixed_base_window=args.fb_window)
-    alice_d = bob_d.public_copy()
-    _ = bob_d.fb_h, alice_d.fb_h  # build the fixed-base tables (untimed set-up, like key generation)
-    x, y, x_enc, y_enc, draws = synth_inputs(eng, l, alice_p, bob_p, bob_d, B, args.rbits, seed=rank)
-
-    # ---- concurrent shards (batch.ConcurrentShards): the batch is cut into `streams` contiguous shards once, outside the timed
-    # region (a caller that produces its inputs per shard pays nothing; cutting a resident batch is one ~1.5 GB device copy)
     ns = max(1, min(args.streams, B)) if args.streams > 0 else (2 if B >= 65536 else 1)
-    runner, shard_inputs, engines = None, None, [eng]
-    if ns > 1:
-        from protocols.secure_comparison_amd.batch import ConcurrentShards, PartySet, split_draws
-        from protocols.secure_comparison_amd.distributed import shard_bounds
-        from protocols.secure_comparison_amd.engine import Engine
+    engines = [eng] + [Engine() for _ in range(1, ns)]
+    for e_ in engines:
+        e_.set_latency_mode(args.latency_mode)
 
-        parties = [PartySet(alice_p, alice_d, bob_p, bob_d, torch.cuda.Stream())]
-        for _ in range(1, ns):
-            e_i = Engine()
-            e_i.set_latency_mode(args.latency_mode)
-            engines.append(e_i)
-            bp_i = Paillier(p * q, p, q, engine=e_i, use_crt=not args.no_crt)
-            bd_i = DGK(bob_d.public_key.n, bob_d.public_key.g, bob_d.public_key.h, bob_d.public_key.u, bob_d.public_key.t,
-                       int(dj["p"], 16), int(dj["q"], 16), int(dj["v_p"], 16), int(dj["v_q"], 16), engine=e_i,
-                       randomizer_bits=args.rbits, fixed_base_window=args.fb_window)
-            ad_i = bd_i.public_copy()
-            _ = bd_i.fb_h, ad_i.fb_h
-            parties.append(PartySet(bp_i.public_copy(), ad_i, bp_i, bd_i, torch.cuda.Stream()))
+    def build_parties(window: int) -> tuple[list[PartySet], float, int]:
+        """Both parties' scheme objects per shard context.  The fixed-base tables are built once (first context) and shared
+        read-only by the others; the key holder, who randomizes through CRT, has no table for h mod n at all."""
+        sets, build_s, table_bytes = [], 0.0, 0
+        for i, e_i in enumerate(engines):
+            bob_p = Paillier(p * q, p, q, engine=e_i, use_crt=use_crt)
+            bob_d = DGK(H("p") * H("q"), H("g"), H("h"), H("u"), dj["t"], H("p"), H("q"), H("v_p"), H("v_q"), engine=e_i,
+                        randomizer_bits=args.rbits, fixed_base_window=window, use_crt=use_crt)
+            alice_d = bob_d.public_copy()
+            if i > 0:
+                bob_d.share_tables_from(sets[0].bob_dgk)
+                alice_d.share_tables_from(sets[0].alice_dgk)
+            _ = alice_d.fb_h                      # untimed set-up, like key generation (SURVEY 8(d): "excluding table build")
+            _ = bob_d._crt_setup() if use_crt else bob_d.fb_h
+            if i == 0:
+                build_s = alice_d.table_build_s + bob_d.table_build_s
+                table_bytes = alice_d.table_bytes() + bob_d.table_bytes()
+            sets.append(PartySet(bob_p.public_copy(), alice_d, bob_p, bob_d, torch.cuda.Stream()))
+        return sets, build_s, table_bytes
+
+    parties, table_build_s, table_bytes = build_parties(args.fb_window)
+    alice_p, alice_d, bob_p, bob_d = parties[0].alice_paillier, parties[0].alice_dgk, parties[0].bob_paillier, parties[0].bob_dgk
+    x, y, x_enc, y_enc, draws = synth_inputs(eng, l, alice_p, bob_p, bob_d, B, args.rbits, seed=rank, shuffle=not args.no_shuffle)
+
+    # ---- concurrent shards (batch.ConcurrentShards): the batch is cut into `ns` contiguous shards once, outside the timed
+    # region (a caller that produces its inputs per shard pays nothing; cutting a resident batch is one ~1.5 GB device copy)
+    shard_inputs = None
+    if ns > 1:
         bounds = [shard_bounds(B, i, ns) for i in range(ns)]
         shard_inputs = [(x_enc[a:b].contiguous(), y_enc[a:b].contiguous(), d) for (a, b), d in zip(bounds, split_draws(draws, bounds))]
-        runner = ConcurrentShards(parties)
         torch.cuda.synchronize()
 
-    def step():
-        if runner is None:
-            return secure_comparison_batch(x_enc, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws, randomize=True)
-        return torch.cat(runner.run(shard_inputs, l, randomize=True), dim=0)
+    def make_step(party_sets):
+        if ns == 1:
+            ps = party_sets[0]
+            return lambda: secure_comparison_batch(x_enc, y_enc, l, ps.alice_paillier, ps.alice_dgk, ps.bob_paillier, ps.bob_dgk, draws,
+                                                   randomize=True)
+        runner = ConcurrentShards(party_sets)
+        return lambda: torch.cat(runner.run(shard_inputs, l, randomize=True), dim=0)
+
+    step = make_step(parties)
 
     def gather(res):
         if dist is None:
@@ -193,37 +253,57 @@ def main() -> None:
         dist.all_gather_into_tensor(out, res.contiguous())
         return out
 
+    def timed(fn, steps):
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r_ = gather(fn())
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=eng.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, r_
+
+    res = None
     for _ in range(args.warmup):
         res = gather(step())
     torch.cuda.synchronize()
     # parity spot check outside the timed region: decrypt the results on the GPU and compare with x <= y
-    if args.warmup:
-        dec = bob_p.decrypt_raw_batch(res[rank * B:(rank + 1) * B] if world > 1 else res)
-        expect = (x <= y).to(torch.int32)
-        ok = bool(((dec[:, 0] == expect) & (dec[:, 1:] == 0).all(dim=1)).all().item())
-        if not ok:
-            raise SystemExit("bench.py: decrypted results differ from x <= y")
+    expect = (x <= y).to(torch.int32)
+
+    def all_correct(full):
+        dec = bob_p.decrypt_raw_batch((full[rank * B:(rank + 1) * B] if world > 1 else full).contiguous())
+        return bool(((dec[:, 0] == expect) & (dec[:, 1:] == 0).all(dim=1)).all().item())
+
+    if res is not None and not all_correct(res):
+        raise SystemExit("bench.py: decrypted results differ from x <= y")
+    rccl_ranks, devices = 1, [torch.cuda.current_device()]
+    if dist is not None:   # prove the collective sees every rank, and where the ranks sit
+        ones = torch.ones(1, dtype=torch.int64, device=eng.device)
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+        ids = torch.zeros(world, dtype=torch.int64, device=eng.device)
+        dist.all_gather_into_tensor(ids, torch.tensor([torch.cuda.current_device()], dtype=torch.int64, device=eng.device))
+        devices = ids.tolist()
+        if rccl_ranks != world:
+            raise SystemExit(f"bench.py: the all-reduce saw {rccl_ranks} ranks, expected {world}")
     [e_.mac_counter(reset=True) for e_ in engines]
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = gather(step())
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, res = timed(step, args.steps)
     executed_macs = sum(e_.mac_counter() for e_ in engines)
     value = world * B * args.steps / elapsed
+    if not all_correct(res):
+        raise SystemExit("bench.py: decrypted results of the timed steps differ from x <= y")
 
     out = None
     if rank == 0:
-        # ---- roofline of the dominant kernel: Alice's Paillier randomizer rho^N mod N^2 (k_vm<8,18>, one launch)
+        # ---- roofline of the dominant kernel: Alice's Paillier randomizer rho^N mod N^2 (k_pvm<4,18> + assembly launch),
+        # timed with HIP events on the stream the library launches on (torch's current stream here)
         reps = 3
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         z_dummy = x_enc
@@ -239,6 +319,7 @@ def main() -> None:
         launch_exec_macs = eng.mac_counter() / reps
         s32 = 2 * args.pbits // 32
         alg_macs = B * (args.pbits + -(-args.pbits // 5) + 30 + 1) * (2 * s32 * s32 + s32)
+        alg_bytes_launch = B * (args.pbits // 8 + 2 * (2 * args.pbits // 8))      # rho in, ciphertext in, ciphertext out
         # ---- modexp/s for the two canonical shapes of SURVEY 8(d): P = Paillier randomizer, D = DGK fixed-base randomizer
         d_exps = draws.r_alice_dgk.reshape((l + 1) * B, -1)
         alice_d.randomize_batch(None, d_exps)
@@ -251,97 +332,134 @@ def main() -> None:
         peak = eng.peak_probe()
         props = torch.cuda.get_device_properties(eng.device)
         nominal_peak = props.multi_processor_count * 64 * MAX_CLOCK_HZ   # 4 SIMDs x 16 lanes per CU, one multiply-add per lane and cycle
-        lit = literal_macs_per_comparison(l, args.pbits, args.pbits, args.rbits)
-        abytes = algorithmic_bytes_per_comparison(l, args.pbits, args.pbits, args.rbits)
+        lit = literal_macs_per_comparison(l, args.pbits, dbits, args.rbits)
+        abytes = algorithmic_bytes_per_comparison(l, args.pbits, dbits, args.rbits)
         # HBM traffic of the dominant launch from the committed PMC pass (rocprofv3 cannot run inside this process)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_dominant_kernel_traffic.json")
-        if os.path.exists(tpath) and B == 65536 and args.pbits == 2048 and l == 32 and not args.no_crt:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        for name in ("r02_dominant_kernel_traffic.json", "r01_dominant_kernel_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(tpath) and B == 65536 and args.pbits == 2048 and l == 32 and use_crt:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                break
+        cfg_name = {(65536, 32, 2048): "BASELINE configs[2]", (4096, 16, 2048): "BASELINE configs[1]", (131072, 32, 2048): "per-GPU share of BASELINE configs[3]",
+                    (32768, 64, 3072): "per-GPU share of BASELINE configs[4]"}.get((B, l, args.pbits), "custom")
         out = {
             "metric": "secure comparisons/sec (l=%d, %d-bit keys)" % (l, args.pbits), "value": value, "unit": "comparisons/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 (29-bit limbs held in u32, 32x32+64->64 multiply-accumulate)",
-            "data": "synthetic",
-            "config": {"workload": "batch %d comparisons per GPU, l=%d, %d-bit Paillier + %d-bit DGK (BASELINE configs[2])" % (B, l, args.pbits, args.pbits),
-                       "batch_per_gpu": B, "l": l, "paillier_bits": args.pbits, "dgk_bits": args.pbits, "dgk_randomizer_bits": args.rbits,
-                       "fixed_base_window": args.fb_window, "keyholder_crt": not args.no_crt, "parallelism": "shard%d" % world,
-                       "streams_per_gpu": ns},
+            "data": "synthetic", "rccl_ranks": rccl_ranks, "rank_devices": devices,
+            "config": {"workload": "batch %d comparisons per GPU, l=%d, %d-bit Paillier + %d-bit DGK (%s)" % (B, l, args.pbits, dbits, cfg_name),
+                       "batch_per_gpu": B, "l": l, "paillier_bits": args.pbits, "dgk_bits": dbits, "dgk_key": dname, "dgk_randomizer_bits": args.rbits,
+                       "fixed_base_window": args.fb_window, "keyholder_crt": use_crt, "shuffle_4i": not args.no_shuffle,
+                       "parallelism": "shard%d" % world, "streams_per_gpu": ns,
+                       "fixed_base_table_bytes": table_bytes, "table_build_s": table_build_s,
+                       "table_note": "device bytes of Alice's table for h mod n plus the key holder's CRT tables for h mod p, h mod q, built once per GPU "
+                                     "(untimed set-up, SURVEY 8(d)) and shared read-only by the %d shard context(s)" % ns},
             "roofline": {"bound": "valu-int",
                          "bound_note": "v_mad_u64_u32 issue rate; neither HBM nor MFMA bounds this path (SURVEY 8(d)); the HBM view is in roofline_hbm",
                          "kernel": "k_pvm<4,18>: Paillier randomizer rho^N mod N^2 for B items, pair arithmetic modulo N (one launch) "
                                    "followed by the k_vm<8,18> launch that assembles w0 + w1 N and multiplies into the ciphertext",
-                         "executed_achieved": launch_exec_macs / launch_s / 1e12, "executed_frac": launch_exec_macs / launch_s / peak,
-                         "peak_nominal": nominal_peak / 1e12, "executed_frac_of_nominal": launch_exec_macs / launch_s / nominal_peak,
-                         "peak_note": "peak = sc_peak_probe (a pure v_mad_u64_u32 stream, measured on this box; it settles at a lower clock than the mixed kernel holds); "
-                                      "peak_nominal = CUs x 4 SIMDs x 16 lanes x 2.4 GHz (MI355X peak engine clock): a wave64 v_mad_u64_u32 occupies its SIMD for 4 cycles",
-                         "note": "achieved uses SURVEY 8(d)'s LITERAL op mix (32-bit-limb CIOS, window-5 modexp mod N^2), so algorithmic savings "
-                                 "(pair arithmetic, symmetric squaring) show up as frac > 1; executed_* counts the 29-bit multiply-adds actually issued",
-                         "achieved": alg_macs / launch_s / 1e12, "peak": peak / 1e12, "unit": "T MAC/s (32x32->64)",
-                         "frac": alg_macs / launch_s / peak, "traffic": traffic,
-                         "traffic_note": "HBM bytes moved per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r01_pmc_summary.csv (separate rocprofv3 --pmc passes; gfx950 tallies each 128-B line request at 64 B, confirmed for this library's limb rows in profiles/r01_traffic_calibration.json)",
-                         "launch_ms": launch_s * 1e3,
-                         "algorithmic_macs_per_launch": alg_macs},
+                         "achieved": launch_exec_macs / launch_s / 1e12, "peak": nominal_peak / 1e12, "unit": "T MAC/s (v_mad_u64_u32 lane operations executed)",
+                         "frac": launch_exec_macs / launch_s / nominal_peak,
+                         "peak_note": "peak = CUs x 4 SIMDs x 16 lanes x 2.4 GHz (MI355X peak engine clock): a wave64 v_mad_u64_u32 occupies its SIMD for 4 cycles; "
+                                      "probe_peak = sc_peak_probe, a pure v_mad_u64_u32 stream measured on this box",
+                         "probe_peak": peak / 1e12, "frac_of_probe": launch_exec_macs / launch_s / peak,
+                         "executed_macs_per_launch": launch_exec_macs,
+                         "literal_opmix_ratio": alg_macs / launch_s / nominal_peak,
+                         "literal_note": "SURVEY 8(d)'s LITERAL op mix (32-bit-limb CIOS, window-5 modexp mod N^2) / launch time / peak: "
+                                         "algorithmic savings (pair arithmetic, symmetric squaring, sliding window 6) push it above frac, and above 1",
+                         "literal_macs_per_launch": alg_macs,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes_launch,
+                         "traffic_note": "HBM bytes moved per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from the committed PMC passes (profiles/; gfx950 tallies each 128-B line request at 64 B, "
+                                         "calibrated on this library's limb rows in profiles/r01_traffic_calibration.json); it exceeds the algorithmic bytes because each item's "
+                                         "window table lives in an HBM scratch arena (DESIGN.md 4)",
+                         "launch_ms": launch_s * 1e3},
             "modexp_per_s": {"P": B / launch_s, "D": d_rate,
                              "shapes": "P: %d-bit base ^ %d-bit exponent mod %d-bit (rho^N mod N^2); D: fixed base, %d-bit exponent mod %d-bit (h^r mod n)"
-                                       % (args.pbits, args.pbits, 2 * args.pbits, args.rbits, args.pbits)},
-            "roofline_whole_step": {"literal_macs_per_comparison": lit, "achieved": lit * value / world / 1e12, "peak": peak / 1e12,
-                                    "unit": "T MAC/s per GPU", "frac": lit * value / world / peak,
-                                    "executed_limb_macs_per_comparison": executed_macs / (B * args.steps),
-                                    "executed_frac": executed_macs / (elapsed * peak)},
+                                       % (args.pbits, args.pbits, 2 * args.pbits, args.rbits, dbits)},
+            "roofline_whole_step": {"executed_macs_per_comparison": executed_macs / (B * args.steps),
+                                    "achieved": executed_macs / elapsed / 1e12, "peak": nominal_peak / 1e12, "unit": "T MAC/s per GPU (executed)",
+                                    "frac": executed_macs / (elapsed * nominal_peak), "frac_of_probe": executed_macs / (elapsed * peak),
+                                    "literal_macs_per_comparison": lit, "literal_opmix_ratio": lit * value / world / nominal_peak},
             "roofline_hbm": {"bound": "hbm", "achieved": abytes * value / world / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": abytes * value / world / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_comparison": abytes},
         }
-        # ---- online phase only (reported, never `value`): randomizers pre-generated into device pools (untimed), as the
-        # reference pre-generates them in background workers (boot_randomness_generation, SC/initiator.py:205-210)
-        gen = torch.Generator(device=eng.device)
-        gen.manual_seed(1234)
-        boot_pools(B, l, alice_p, alice_d, bob_p, bob_d, source="torch", generator=gen)
-        torch.cuda.synchronize()
-        to = time.perf_counter()
-        ro = secure_comparison_batch(x_enc, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws, randomize="pool")
-        torch.cuda.synchronize()
-        online_s = time.perf_counter() - to
-        dec_o = bob_p.decrypt_raw_batch(ro)
-        out["online_phase_only"] = {"value": B / online_s, "unit": "comparisons/s", "correct": bool((dec_o[:, 0] == (x <= y).to(torch.int32)).all().item()),
-                                    "note": "all 4 + 2(l+1) randomizer exponentiations per comparison pre-generated (excluded); informational"}
-        # ---- PCIe-inclusive rate (reported at N = 1, never `value`): inputs start in pinned host memory, result returns to the host
-        if world == 1:
-            host_in = [t.cpu().pin_memory() for t in (x_enc, y_enc, draws.r, draws.delta_a, draws.rhos, draws.rho_z, draws.r_bob_dgk,
-                                                      draws.r_alice_dgk, draws.rho_zeta_1, draws.rho_zeta_2, draws.rho_delta_b)]
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N = 1 only
+            cores = min(os.cpu_count() or 1, 16)
+            sample = min(B, args.cpu_sample or 64 * cores)
+            py = "/opt/conda/bin/python3.9" if os.path.exists("/opt/conda/bin/python3.9") else sys.executable
+            try:
+                stride = max(1, B // sample)
+                idx = [i * stride for i in range(sample)]
+                with tempfile.TemporaryDirectory() as td:
+                    path = os.path.join(td, "sample.json")
+                    export_sample(path, eng, idx, l, x_enc, y_enc, draws, res)
+
+                    def cpu_run(interp, count, procs):
+                        cp = subprocess.run([interp, os.path.join(ROOT, "oracle", "cpu_baseline.py"), KEYS, f"paillier_{args.pbits}", dname,
+                                             str(count), str(procs), str(args.rbits), path], capture_output=True, text=True, timeout=900)
+                        if cp.returncode != 0:
+                            raise RuntimeError(cp.stderr.strip().splitlines()[-1] if cp.stderr.strip() else "cpu baseline failed")
+                        return json.loads(cp.stdout.strip().splitlines()[-1])
+
+                    cb = cpu_run(py, sample, cores)
+                    out["cpu_baseline"] = {"value": cb["value"], "unit": "comparisons/s", "cores": cb["cores"], "kind": "port",
+                                           "sample": "%d comparisons of the SAME seeded batch (every %d-th row: inputs and all random draws downloaded from the GPU), "
+                                                     "oracle.compare with %s over %d processes; %d/%d results equal the GPU's bit for bit"
+                                                     % (cb["count"], stride, cb["arith"], cb["cores"], cb["match_gpu"], cb["count"])}
+                    one = cpu_run(py, 8, 1)                       # single-core figure
+                    out["cpu_baseline"]["single_core"] = {"value": one["value"], "arith": one["arith"], "sample": one["count"]}
+                    if py != sys.executable:                      # and the pure-Python-int path of the default interpreter
+                        pure = cpu_run(sys.executable, 2 * cores, cores)
+                        out["cpu_baseline"]["python_int"] = {"value": pure["value"], "cores": pure["cores"], "arith": pure["arith"], "sample": pure["count"]}
+                    if cb["match_gpu"] != cb["count"]:
+                        raise SystemExit("bench.py: the CPU oracle and the GPU disagree on the sampled comparisons")
+            except SystemExit:
+                raise
+            except Exception as exc:  # pragma: no cover
+                out["cpu_baseline"] = {"value": None, "unit": "comparisons/s", "cores": cores, "kind": "port", "sample": f"failed: {exc}"}
+        if not args.no_extras and world == 1:
+            # ---- how much of `value` hangs on the 6 GB window-20 table: the same step with smaller fixed-base windows
+            sens = {str(args.fb_window): {"value": value, "table_bytes": table_bytes, "table_build_s": table_build_s}}
+            for w in (8, 16):
+                if w == args.fb_window:
+                    continue
+                ps_w, bs_w, tb_w = build_parties(w)
+                step_w = make_step(ps_w)
+                step_w()
+                dt_w, _ = timed(step_w, 2)
+                sens[str(w)] = {"value": B * 2 / dt_w, "table_bytes": tb_w, "table_build_s": bs_w}
+                del ps_w, step_w
+            out["window_sensitivity"] = sens
+            # ---- online phase only (reported, never `value`): randomizers pre-generated into device pools (untimed), as the
+            # reference pre-generates them in background workers (boot_randomness_generation, SC/initiator.py:205-210)
+            gen = torch.Generator(device=eng.device)
+            gen.manual_seed(1234)
+            boot_pools(B, l, alice_p, alice_d, bob_p, bob_d, source="torch", generator=gen)
+            torch.cuda.synchronize()
+            to = time.perf_counter()
+            ro = secure_comparison_batch(x_enc, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws, randomize="pool")
+            torch.cuda.synchronize()
+            online_s = time.perf_counter() - to
+            dec_o = bob_p.decrypt_raw_batch(ro)
+            out["online_phase_only"] = {"value": B / online_s, "unit": "comparisons/s", "correct": bool((dec_o[:, 0] == expect).all().item()),
+                                        "note": "all 4 + 2(l+1) randomizer exponentiations per comparison pre-generated (excluded); informational"}
+            # ---- PCIe-inclusive rate (reported at N = 1, never `value`): inputs start in pinned host memory, result returns to the host
+            names = ("r", "delta_a", "rhos", "rho_z", "r_bob_dgk", "r_alice_dgk", "rho_zeta_1", "rho_zeta_2", "rho_delta_b")
+            host_in = [t.cpu().pin_memory() for t in (x_enc, y_enc) + tuple(getattr(draws, n_) for n_ in names)]
+            host_perm = None if draws.permutation is None else draws.permutation.cpu().pin_memory()
             for _ in range(2):                                # the first pass pays for the allocator's first-time hipMallocs
                 torch.cuda.synchronize()
                 tp = time.perf_counter()
                 dv = [t.to(eng.device, non_blocking=True) for t in host_in]
-                d2 = BatchDraws(r=dv[2], delta_a=dv[3], rhos=dv[4], permutation=None, rho_z=dv[5], r_bob_dgk=dv[6], r_alice_dgk=dv[7],
-                                rho_zeta_1=dv[8], rho_zeta_2=dv[9], rho_delta_b=dv[10])
+                d2 = BatchDraws(permutation=None if host_perm is None else host_perm.to(eng.device, non_blocking=True),
+                                **{n_: dv[2 + i] for i, n_ in enumerate(names)})
                 r2 = secure_comparison_batch(dv[0], dv[1], l, alice_p, alice_d, bob_p, bob_d, d2, randomize=True).cpu()
                 torch.cuda.synchronize()
                 pcie_s = time.perf_counter() - tp
                 del dv, d2
             out["pcie_inclusive"] = {"value": B / pcie_s, "unit": "comparisons/s", "host_bytes_per_comparison":
                                      sum(t.numel() * t.element_size() for t in host_in) / B + r2.shape[-1] * 4}
-        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N = 1 only
-            cores = min(os.cpu_count() or 1, 16)
-            sample = args.cpu_sample or 64 * cores
-            py = "/opt/conda/bin/python3.9" if os.path.exists("/opt/conda/bin/python3.9") else sys.executable
-            def cpu_run(interp, count, procs):
-                cp = subprocess.run([interp, os.path.join(ROOT, "oracle", "cpu_baseline.py"), KEYS, f"paillier_{args.pbits}", dname,
-                                     str(count), str(procs), str(args.rbits)], capture_output=True, text=True, timeout=600)
-                return json.loads(cp.stdout.strip().splitlines()[-1])
-
-            try:
-                cb = cpu_run(py, sample, cores)
-                out["cpu_baseline"] = {"value": cb["value"], "unit": "comparisons/s", "cores": cb["cores"], "kind": "port",
-                                       "sample": "%d comparisons of the same workload (oracle.compare, %s) over %d processes; %d/%d correct"
-                                                 % (cb["count"], cb["arith"], cb["cores"], cb["correct"], cb["count"])}
-                one = cpu_run(py, 8, 1)                       # single-core figure
-                out["cpu_baseline"]["single_core"] = {"value": one["value"], "arith": one["arith"], "sample": one["count"]}
-                if py != sys.executable:                      # and the pure-Python-int path of the default interpreter
-                    pure = cpu_run(sys.executable, 2 * cores, cores)
-                    out["cpu_baseline"]["python_int"] = {"value": pure["value"], "cores": pure["cores"], "arith": pure["arith"], "sample": pure["count"]}
-            except Exception as exc:  # pragma: no cover
-                out["cpu_baseline"] = {"value": None, "unit": "comparisons/s", "cores": cores, "kind": "port", "sample": f"failed: {exc}"}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

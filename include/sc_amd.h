@@ -17,8 +17,10 @@
  *   - Calls are asynchronous on the context's stream (sc_ctx_set_stream) unless stated otherwise.
  *   - No function falls back to host arithmetic: without a gfx950 device every call fails.
  *   - A context belongs to one host thread at a time and orders all its work on one stream; its temporary device buffers are
- *     reused from call to call, so a caller that changes the stream between calls must order the streams itself.  Use one
- *     context per GPU (one process per GPU under torch.distributed).
+ *     reused from call to call.  sc_ctx_set_stream orders the work already queued on the previous stream before anything
+ *     queued on the new one (event wait, no host synchronisation), so alternating streams on one context is safe; the
+ *     caller's own input / output buffers follow the usual stream rules.  Use one context per GPU (one process per GPU under
+ *     torch.distributed), or one per concurrent shard of a GPU.
  */
 #ifndef SC_AMD_H
 #define SC_AMD_H
@@ -69,6 +71,12 @@ int sc_const_create(sc_ctx* ctx, int mod, const uint32_t* v_hptr, int nwords, in
 /* Build the fixed-base table base^(d * 2^(window*j)) for exponents below 2^exp_bits
  * (DGK h and g: the randomizers h^r of SC/initiator.py:153-154 and SC/keyholder.py:106-108). */
 int sc_fbt_create(sc_ctx* ctx, int mod, const uint32_t* base_hptr, int exp_bits, int window, int* out_fbt);
+/* Use a table another context of the same device built for the same modulus (a window-20 table for h is 6 GB: concurrent
+ * shard contexts of one GPU read one copy).  The rows are read-only and reference-counted: they are freed when the last
+ * context holding the table is destroyed.  `mod` must be `ctx`'s registration of the modulus the table was built for. */
+int sc_fbt_import(sc_ctx* ctx, int mod, sc_ctx* src_ctx, int src_fbt, int* out_fbt);
+/* Device bytes of a table's rows (reported by bench.py next to the throughput that depends on them). */
+int sc_fbt_bytes(sc_ctx* ctx, int fbt, uint64_t* out_bytes);
 
 /* ---- batched residue arithmetic (the ciphertext operator algebra) ---------------- */
 /* out[i] = a[i] * b[i] mod n.  Stride 0 broadcasts a single residue.  ct + ct (SC/initiator.py:254,
@@ -107,7 +115,8 @@ int sc_modexp_var(sc_ctx* ctx, int mod, const uint32_t* x_dptr, const uint32_t* 
                   uint64_t count);
 /* out[i] = x[i]^-1 mod n (Montgomery's simultaneous inversion + an on-device binary extended GCD):
  * ct * -1 / int - ct / ct - ct (SC/initiator.py:254, 320, 371, 466, 478, 531, 559).
- * Synchronous.  On SC_ERR_NOT_INVERTIBLE *bad_index (nullable) is an index of a non-invertible element. */
+ * Synchronous.  On SC_ERR_NOT_INVERTIBLE *bad_index (nullable) is the index of a non-invertible element (found by testing
+ * the members of the failing chunk individually) and sc_last_error() names it; `out` is unspecified then. */
 int sc_modinv(sc_ctx* ctx, int mod, const uint32_t* x_dptr, uint32_t* out_dptr, uint64_t count,
               int64_t* bad_index);
 

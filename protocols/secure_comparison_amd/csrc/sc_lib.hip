@@ -116,7 +116,12 @@ struct Mod {
 };
 struct Exp { Big e; int bits = 0; };
 struct Const { int mod = -1; uint32_t* d_limbs = nullptr; };
-struct Fbt { int mod = -1, window = 0, nwin = 0, exp_bits = 0; uint32_t* d_rows = nullptr; };
+// the rows of a fixed-base table are shared between contexts (sc_fbt_import): freed when the last table that uses them goes
+struct FbtRows {
+  int device = 0; uint32_t* d = nullptr; size_t bytes = 0;
+  ~FbtRows() { if (d) { (void)hipSetDevice(device); (void)hipFree(d); } }
+};
+struct Fbt { int mod = -1, window = 0, nwin = 0, exp_bits = 0; uint32_t* d_rows = nullptr; std::shared_ptr<FbtRows> rows; };
 struct Prog {
   uint32_t nops = 0, nscratch = 1, nconst = 0;
   VmOp* d_ops = nullptr;
@@ -131,6 +136,7 @@ struct Prog {
 struct sc_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipEvent_t switch_event = nullptr;   // orders the work of the previous stream before the next one (sc_ctx_set_stream)
   int num_cu = 256;
   std::string err;
   std::vector<Mod> mods;
@@ -202,7 +208,7 @@ int tmp_buf(sc_ctx* ctx, int slot, size_t bytes, void** out) {
   *out = e.first;
   return SC_OK;
 }
-enum TmpSlot { TMP_PARK = 1, TMP_XGCD_STATUS = 2, TMP_CRT = 3, TMP_PAIR = 4, TMP_INV_BASE = 16 /* + 2*depth, + 2*depth+1 */ };
+enum TmpSlot { TMP_PARK = 1, TMP_XGCD_STATUS = 2, TMP_CRT = 3, TMP_PAIR = 4, TMP_INV_MEMBERS = 5, TMP_INV_BASE = 16 /* + 2*depth, + 2*depth+1 */ };
 
 // device copy of n | (n-1)/2 as canonical words (plain-word kernels)
 int device_n_half(sc_ctx* ctx, const uint32_t* n_hptr, int nw, uint32_t** out) {
@@ -519,6 +525,7 @@ void sc_ctx_destroy(sc_ctx* ctx) {
   for (void* p : ctx->owned) (void)hipFree(p);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   for (auto& kv : ctx->tmp) if (kv.second.first) (void)hipFree(kv.second.first);
+  if (ctx->switch_event) (void)hipEventDestroy(ctx->switch_event);
   delete ctx;
 }
 
@@ -527,7 +534,22 @@ int sc_ctx_set_latency_mode(sc_ctx* ctx, int mode) {
   ctx->latency_mode = mode;
   return SC_OK;
 }
-int sc_ctx_set_stream(sc_ctx* ctx, void* hip_stream) { if (!ctx) return SC_ERR_ARG; ctx->stream = (hipStream_t)hip_stream; return SC_OK; }
+// The context reuses its scratch arena, temporaries and parked tables from call to call, so work queued on the previous stream
+// must be ordered before anything the next stream does with them: an event recorded on the old stream, waited for on the new.
+int sc_ctx_set_stream(sc_ctx* ctx, void* hip_stream) {
+  if (!ctx) return SC_ERR_ARG;
+  hipStream_t s = (hipStream_t)hip_stream;
+  if (s == ctx->stream) return SC_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (!ctx->switch_event) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->switch_event, hipEventDisableTiming));
+  if (hipEventRecord(ctx->switch_event, ctx->stream) == hipSuccess) {
+    HIPCHK(ctx, hipStreamWaitEvent(s, ctx->switch_event, 0));
+  } else {
+    (void)hipGetLastError();                       // the previous stream no longer exists: its work was completed when it was destroyed
+  }
+  ctx->stream = s;
+  return SC_OK;
+}
 int sc_ctx_synchronize(sc_ctx* ctx) { if (!ctx) return SC_ERR_ARG; HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); return SC_OK; }
 const char* sc_last_error(sc_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
@@ -738,7 +760,12 @@ int sc_fbt_create(sc_ctx* ctx, int mod, const uint32_t* base_hptr, int exp_bits,
   const Mod& m = ctx->mods[mod];
   Fbt f; f.mod = mod; f.window = window; f.exp_bits = exp_bits; f.nwin = (exp_bits + window - 1) / window;
   const uint64_t rows = (uint64_t)f.nwin << window;
-  int rc = dev_alloc(ctx, rows * m.S * 4, (void**)&f.d_rows); if (rc) return rc;
+  f.rows = std::make_shared<FbtRows>();
+  f.rows->device = ctx->device; f.rows->bytes = rows * m.S * 4;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMalloc((void**)&f.rows->d, f.rows->bytes));
+  f.d_rows = f.rows->d;
+  int rc;
   int cbase; rc = sc_const_create(ctx, mod, base_hptr, m.nwords, &cbase); if (rc) return rc;
   // stage A: B_j = base^(2^(window j)), limb form, one item
   uint32_t* d_B; rc = dev_alloc(ctx, (size_t)f.nwin * m.S * 4, (void**)&d_B); if (rc) return rc;
@@ -776,6 +803,28 @@ int sc_fbt_create(sc_ctx* ctx, int mod, const uint32_t* base_hptr, int exp_bits,
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->fbts.push_back(f);
   *out_fbt = (int)ctx->fbts.size() - 1;
+  return SC_OK;
+}
+
+int sc_fbt_import(sc_ctx* ctx, int mod, sc_ctx* src_ctx, int src_fbt, int* out_fbt) {
+  if (!valid_mod(ctx, mod) || !src_ctx || src_fbt < 0 || src_fbt >= (int)src_ctx->fbts.size() || !out_fbt)
+    return fail(ctx, SC_ERR_ARG, "sc_fbt_import: bad argument");
+  const Fbt& sf = src_ctx->fbts[src_fbt];
+  const Mod& sm = src_ctx->mods[sf.mod];
+  const Mod& m = ctx->mods[mod];
+  if (src_ctx->device != ctx->device) return fail(ctx, SC_ERR_ARG, "sc_fbt_import: the table lives on another device");
+  if (sm.G != m.G || sm.L != m.L || sm.W != m.W || sm.n != m.n)
+    return fail(ctx, SC_ERR_ARG, "sc_fbt_import: the table was built for another modulus");
+  Fbt f = sf;            // shares the rows (reference-counted); read-only from here on
+  f.mod = mod;
+  ctx->fbts.push_back(f);
+  *out_fbt = (int)ctx->fbts.size() - 1;
+  return SC_OK;
+}
+
+int sc_fbt_bytes(sc_ctx* ctx, int fbt, uint64_t* out_bytes) {
+  if (!ctx || fbt < 0 || fbt >= (int)ctx->fbts.size() || !out_bytes) return fail(ctx, SC_ERR_ARG, "sc_fbt_bytes: bad argument");
+  *out_bytes = ctx->fbts[fbt].rows ? (uint64_t)ctx->fbts[fbt].rows->bytes : 0;
   return SC_OK;
 }
 
@@ -976,7 +1025,28 @@ static int modinv_rec(sc_ctx* ctx, int mod, const uint32_t* x, uint32_t* out, ui
                    mk_ext(d_totinv, m.nwords, m.nwords), mk_ext(out, m.nwords, m.nwords, count)};
     rc = run_vm(ctx, mod, it2->second, ex, 5, C);
   }
-  if (rc == SC_ERR_NOT_INVERTIBLE && bad && bad_chunk >= 0) *bad = bad_chunk;  // index of a chunk member
+  if (rc == SC_ERR_NOT_INVERTIBLE && bad_chunk >= 0) {
+    // The product of chunk `bad_chunk` (members x[i C + bad_chunk], i < K) is not invertible: test its members one by one
+    // with the extended GCD and report the first that fails, like the reference's pow / gmpy2.invert name the operand.
+    uint64_t members = 0;
+    while (members < K && members * C + (uint64_t)bad_chunk < count) members++;
+    uint32_t* d_m = nullptr; int* d_status = nullptr; uint32_t* d_nw = nullptr;
+    { int rc0 = tmp_buf(ctx, TMP_INV_MEMBERS, (size_t)members * m.nwords * 4 * 2, (void**)&d_m); if (rc0) return rc0; }
+    { int rc0 = tmp_buf(ctx, TMP_XGCD_STATUS, sizeof(int) * members, (void**)&d_status); if (rc0) return rc0; }
+    { int rc0 = device_n_half(ctx, m.n.data(), m.nwords, &d_nw); if (rc0) return rc0; }
+    HIPCHK(ctx, hipMemcpy2DAsync(d_m, (size_t)m.nwords * 4, x + (size_t)bad_chunk * m.nwords, (size_t)C * m.nwords * 4,
+                                 (size_t)m.nwords * 4, members, hipMemcpyDeviceToDevice, ctx->stream));
+    if (launch_xgcd(ctx->stream, d_m, d_m + (size_t)members * m.nwords, d_nw, m.nwords, members, d_status) != 0)
+      return fail(ctx, SC_ERR_HIP, "xgcd launch failed");
+    std::vector<int> st(members);
+    HIPCHK(ctx, hipMemcpyAsync(st.data(), d_status, sizeof(int) * members, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    int64_t first = -1;
+    for (uint64_t i = 0; i < members && first < 0; i++) if (st[i] != 1) first = (int64_t)(i * C + (uint64_t)bad_chunk);
+    if (first < 0) return fail(ctx, SC_ERR_HIP, "sc_modinv: chunk %lld is not invertible but all of its members are", (long long)bad_chunk);
+    if (bad) *bad = first;
+    return fail(ctx, SC_ERR_NOT_INVERTIBLE, "element %lld is not invertible", (long long)first);
+  }
   return rc;
 }
 

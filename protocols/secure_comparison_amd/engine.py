@@ -18,7 +18,11 @@ ScError = _lib.ScError
 
 
 class NotInvertibleError(ZeroDivisionError):
-    """An element of a batch has no modular inverse (the reference's pow/gmpy2 raise likewise)."""
+    """An element of a batch has no modular inverse (the reference's pow/gmpy2 raise likewise); `index` names it."""
+
+    def __init__(self, msg: str, index: int = -1) -> None:
+        super().__init__(msg)
+        self.index = index
 
 
 @dataclass(frozen=True)
@@ -53,6 +57,8 @@ class Engine:
         self._mods: dict[tuple[int, int], Modulus] = {}
         self._exps: dict[int, int] = {}
         self._consts: dict[tuple[int, int], int] = {}
+        self._crt_k: dict[tuple[int, int], int] = {}          # (m_q, m_p) -> m_q^-1 mod m_p
+        self._host_n: dict[tuple[int, int], tuple] = {}       # (n, nwords) -> (array, pointer) kept alive for the plain-word kernels
 
     def close(self) -> None:
         if getattr(self, "ctx", None):
@@ -83,9 +89,41 @@ class Engine:
     def _ptr(t: torch.Tensor | None) -> C.c_void_p:
         return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
 
+    def _arr(self, t: torch.Tensor | None, name: str, rows: int | None = None, words: int | None = None, *, dtype=torch.int32,
+             optional: bool = False, broadcast: bool = False) -> torch.Tensor | None:
+        """The kernels read `rows * words` elements from a raw pointer: refuse anything that is not exactly that array
+        (peer-supplied tensors reach this layer, SC/initiator.py:125-134 receives typed ciphertext objects instead)."""
+        if t is None:
+            if optional:
+                return None
+            raise ValueError(f"{name}: missing array")
+        if not isinstance(t, torch.Tensor):
+            raise ValueError(f"{name}: expected a torch tensor, got {type(t).__name__}")
+        if t.dtype != dtype:
+            raise ValueError(f"{name}: dtype {t.dtype}, expected {dtype}")
+        if t.device != self.device:
+            raise ValueError(f"{name}: lives on {t.device}, the engine works on {self.device}")
+        if not t.is_contiguous():
+            raise ValueError(f"{name}: not contiguous")
+        if t.dim() < 1:
+            raise ValueError(f"{name}: scalar tensor")
+        if words is not None and t.shape[-1] != words:
+            raise ValueError(f"{name}: {t.shape[-1]} words per item, expected {words}")
+        if rows is not None:
+            have = t.numel() // max(1, t.shape[-1]) if words is not None or t.dim() > 1 else t.numel()
+            if not (have == rows or (broadcast and have == 1)):
+                raise ValueError(f"{name}: {have} items, expected {rows}")
+        return t
+
     def _host_words(self, x: int, nwords: int):
         arr = int_to_words(x, nwords)
         return arr, arr.ctypes.data_as(C.c_void_p)
+
+    def _host_n_words(self, n: int, nwords: int):
+        key = (n, nwords)
+        if key not in self._host_n:
+            self._host_n[key] = self._host_words(n, nwords)
+        return self._host_n[key]
 
     def upload(self, xs: Iterable[int], nwords: int) -> torch.Tensor:
         arr = ints_to_words(xs, nwords)
@@ -142,30 +180,54 @@ class Engine:
         self._check(self.lib.sc_fbt_create(self.ctx, mod.id, p, exp_bits, window, C.byref(fid)))
         return FixedBase(fid.value, mod, exp_bits, window)
 
+    def fixed_base_import(self, mod: Modulus, other: "Engine", fb: FixedBase) -> FixedBase:
+        """Use a table that `other` (another library context on the same GPU) built for the same modulus: no second copy."""
+        if other is self:
+            return fb
+        fid = C.c_int()
+        self._check(self.lib.sc_fbt_import(self.ctx, mod.id, other.ctx, fb.id, C.byref(fid)))
+        return FixedBase(fid.value, mod, fb.exp_bits, fb.window)
+
+    def fixed_base_bytes(self, fb: FixedBase) -> int:
+        v = C.c_uint64()
+        self._check(self.lib.sc_fbt_bytes(self.ctx, fb.id, C.byref(v)))
+        return int(v.value)
+
     # ------------------------------------------------------------------ batched residue arithmetic
     @staticmethod
-    def _stride(t: torch.Tensor, count: int) -> int:
-        return 0 if (t.dim() == 1 or t.shape[0] == 1) and count != 1 else t.shape[-1]
+    def _items(t: torch.Tensor) -> int:
+        return t.numel() // max(1, t.shape[-1]) if t.dim() > 1 else 1
+
+    def _out(self, out: torch.Tensor | None, count: int, nwords: int) -> torch.Tensor:
+        return self.empty(count, nwords) if out is None else self._arr(out, "out", count, nwords)
 
     def modmul(self, mod: Modulus, a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
-        count = max(a.shape[0] if a.dim() > 1 else 1, b.shape[0] if b.dim() > 1 else 1)
-        out = self.empty(count, mod.nwords) if out is None else out
+        """a, b: [count][nwords] or a single residue ([nwords] / [1][nwords]) that is broadcast."""
+        count = max(self._items(a), self._items(b))
+        self._arr(a, "a", count, mod.nwords, broadcast=True)
+        self._arr(b, "b", count, mod.nwords, broadcast=True)
+        out = self._out(out, count, mod.nwords)
+        stride = lambda t: 0 if self._items(t) == 1 and count != 1 else mod.nwords  # noqa: E731
         self._sync_stream()
-        self._check(self.lib.sc_modmul(self.ctx, mod.id, self._ptr(a), self._stride(a, count), self._ptr(b),
-                                       self._stride(b, count), self._ptr(out), count))
+        self._check(self.lib.sc_modmul(self.ctx, mod.id, self._ptr(a), stride(a), self._ptr(b), stride(b), self._ptr(out), count))
         return out
 
     def modmul_const(self, mod: Modulus, a: torch.Tensor, c: int, out: torch.Tensor | None = None) -> torch.Tensor:
-        count = a.shape[0]
-        out = self.empty(count, mod.nwords) if out is None else out
+        count = self._items(a)
+        self._arr(a, "a", count, mod.nwords)
+        out = self._out(out, count, mod.nwords)
         self._sync_stream()
         self._check(self.lib.sc_modmul_const(self.ctx, mod.id, self._ptr(a), self.constant(mod, c), self._ptr(out), count))
         return out
 
     def modexp_shared(self, mod: Modulus, x: torch.Tensor, e: int, mul_into: torch.Tensor | None = None,
                       out: torch.Tensor | None = None) -> torch.Tensor:
-        count = x.shape[0]
-        out = self.empty(count, mod.nwords) if out is None else out
+        """x^e mod n for an exponent shared by the batch (key-derived: N, lambda, p - 1, v_p, ...: each distinct exponent is
+        registered once and its program kept; per-ciphertext scalars go through modexp_var)."""
+        count = self._items(x)
+        self._arr(x, "x", count)
+        self._arr(mul_into, "mul_into", count, mod.nwords, optional=True)
+        out = self._out(out, count, mod.nwords)
         self._sync_stream()
         self._check(self.lib.sc_modexp_shared(self.ctx, mod.id, self.exponent(e), self._ptr(x), x.shape[-1],
                                               self._ptr(mul_into), self._ptr(out), count))
@@ -178,15 +240,18 @@ class Engine:
     def modexp_shared_sq(self, mod_m: Modulus, mod_m2: Modulus, x: torch.Tensor, e: int, mul_into: torch.Tensor | None = None,
                          out: torch.Tensor | None = None) -> torch.Tensor:
         """x^e mod m^2 [* mul_into] via pair arithmetic modulo m (identical residues, ~0.6x the multiply-adds)."""
-        count = x.shape[0]
-        out = self.empty(count, mod_m2.nwords) if out is None else out
+        count = self._items(x)
+        self._arr(x, "x", count)
+        self._arr(mul_into, "mul_into", count, mod_m2.nwords, optional=True)
+        out = self._out(out, count, mod_m2.nwords)
         self._sync_stream()
         self._check(self.lib.sc_modexp_shared_sq(self.ctx, mod_m.id, mod_m2.id, self.exponent(e), self._ptr(x), x.shape[-1],
                                                  self._ptr(mul_into), self._ptr(out), count))
         return out
 
     def modexp_shared_isone(self, mod: Modulus, x: torch.Tensor, e: int) -> torch.Tensor:
-        count = x.shape[0]
+        count = self._items(x)
+        self._arr(x, "x", count)
         flags = torch.empty((count,), dtype=torch.uint8, device=self.device)
         self._sync_stream()
         self._check(self.lib.sc_modexp_shared_isone(self.ctx, mod.id, self.exponent(e), self._ptr(x), x.shape[-1],
@@ -195,8 +260,10 @@ class Engine:
 
     def fixedbase_pow(self, fb: FixedBase, e: torch.Tensor, mul_into: torch.Tensor | None = None,
                       out: torch.Tensor | None = None) -> torch.Tensor:
-        count = e.shape[0]
-        out = self.empty(count, fb.mod.nwords) if out is None else out
+        count = self._items(e)
+        self._arr(e, "e", count)
+        self._arr(mul_into, "mul_into", count, fb.mod.nwords, optional=True)
+        out = self._out(out, count, fb.mod.nwords)
         self._sync_stream()
         self._check(self.lib.sc_fixedbase_pow(self.ctx, fb.id, self._ptr(e), e.shape[-1], self._ptr(mul_into),
                                               self._ptr(out), count))
@@ -204,8 +271,11 @@ class Engine:
 
     def modexp_var(self, mod: Modulus, x: torch.Tensor, e: torch.Tensor, ebits: int, fb: FixedBase | None = None,
                    e2: torch.Tensor | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
-        count = x.shape[0]
-        out = self.empty(count, mod.nwords) if out is None else out
+        count = self._items(x)
+        self._arr(x, "x", count, mod.nwords)
+        self._arr(e, "e", count)
+        self._arr(e2, "e2", count, optional=fb is None)
+        out = self._out(out, count, mod.nwords)
         self._sync_stream()
         self._check(self.lib.sc_modexp_var(self.ctx, mod.id, self._ptr(x), self._ptr(e), e.shape[-1], ebits,
                                            -1 if fb is None else fb.id, self._ptr(e2), 0 if e2 is None else e2.shape[-1],
@@ -213,16 +283,21 @@ class Engine:
         return out
 
     def modinv(self, mod: Modulus, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
-        count = x.shape[0]
-        out = self.empty(count, mod.nwords) if out is None else out
+        count = self._items(x)
+        self._arr(x, "x", count, mod.nwords)
+        out = self._out(out, count, mod.nwords)
         self._sync_stream()
         bad = C.c_int64(-1)
-        self._check(self.lib.sc_modinv(self.ctx, mod.id, self._ptr(x), self._ptr(out), count, C.byref(bad)))
+        rc = self.lib.sc_modinv(self.ctx, mod.id, self._ptr(x), self._ptr(out), count, C.byref(bad))
+        if rc == -3:
+            raise NotInvertibleError(self.lib.sc_last_error(self.ctx).decode(), int(bad.value))
+        self._check(rc)
         return out
 
     def paillier_encrypt_raw(self, mod_n2: Modulus, n: int, m: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
-        count = m.shape[0]
-        out = self.empty(count, mod_n2.nwords) if out is None else out
+        count = self._items(m)
+        self._arr(m, "m", count)
+        out = self._out(out, count, mod_n2.nwords)
         self._sync_stream()
         self._check(self.lib.sc_paillier_encrypt_raw(self.ctx, mod_n2.id, self.constant(mod_n2, n), self._ptr(m),
                                                      m.shape[-1], self._ptr(out), count))
@@ -230,16 +305,18 @@ class Engine:
 
     def paillier_encrypt_raw_neg(self, mod_n2: Modulus, n: int, m: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
         """[[-m]] = 1 - m N mod N^2 (the inverse of paillier_encrypt_raw's result, without an inversion)."""
-        count = m.shape[0]
-        out = self.empty(count, mod_n2.nwords) if out is None else out
+        count = self._items(m)
+        self._arr(m, "m", count)
+        out = self._out(out, count, mod_n2.nwords)
         self._sync_stream()
         self._check(self.lib.sc_paillier_encrypt_raw_neg(self.ctx, mod_n2.id, self.constant(mod_n2, n), self._ptr(m),
                                                          m.shape[-1], self._ptr(out), count))
         return out
 
     def paillier_l_mul(self, mod: Modulus, k: int, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
-        count = x.shape[0]
-        out = self.empty(count, mod.nwords) if out is None else out
+        count = self._items(x)
+        self._arr(x, "x", count)
+        out = self._out(out, count, mod.nwords)
         self._sync_stream()
         self._check(self.lib.sc_paillier_l_mul(self.ctx, mod.id, self.constant(mod, k), self._ptr(x), x.shape[-1],
                                                self._ptr(out), count))
@@ -248,9 +325,14 @@ class Engine:
     def crt_combine(self, mod_p: Modulus, mod_full: Modulus, mq: int, a_p: torch.Tensor, a_q: torch.Tensor,
                     out: torch.Tensor | None = None) -> torch.Tensor:
         """x with x = a_p (mod m_p), x = a_q (mod m_q), m_p m_q = mod_full.n (CRT recombination on the GPU)."""
-        count = a_p.shape[0]
-        out = self.empty(count, mod_full.nwords) if out is None else out
-        k = pow(mq, -1, mod_p.n)
+        count = self._items(a_p)
+        self._arr(a_p, "a_p", count)
+        self._arr(a_q, "a_q", count)
+        out = self._out(out, count, mod_full.nwords)
+        key = (mq, mod_p.n)
+        if key not in self._crt_k:
+            self._crt_k[key] = pow(mq, -1, mod_p.n)
+        k = self._crt_k[key]
         self._sync_stream()
         self._check(self.lib.sc_crt_combine(self.ctx, mod_p.id, mod_full.id, self.constant(mod_p, k), self.constant(mod_p, mod_p.n - k),
                                             self.constant(mod_full, mq), self._ptr(a_p), a_p.shape[-1], self._ptr(a_q), a_q.shape[-1],
@@ -258,25 +340,31 @@ class Engine:
         return out
 
     def plain_alice(self, r: torch.Tensor, n: int, l: int):
+        self._arr(r, "r")
+        if r.dim() != 2:
+            raise ValueError("r: expected [count][nwords]")
         count, nw = r.shape
         m1 = self.empty(count, nw + 1)
         alpha = torch.empty((count,), dtype=torch.int64, device=self.device)
         alpha_t = torch.empty_like(alpha)
         rsmall = torch.empty_like(alpha)
         rshift = self.empty(count, nw)
-        arr, p = self._host_words(n, nw)
+        arr, p = self._host_n_words(n, nw)
         self._sync_stream()
         self._check(self.lib.sc_plain_alice(self.ctx, self._ptr(r), p, nw, l, count, self._ptr(m1), self._ptr(alpha),
                                             self._ptr(alpha_t), self._ptr(rsmall), self._ptr(rshift)))
         return m1, alpha, alpha_t, rsmall, rshift
 
     def plain_bob(self, z: torch.Tensor, n: int, l: int):
+        self._arr(z, "z")
+        if z.dim() != 2:
+            raise ValueError("z: expected [count][nwords]")
         count, nw = z.shape
         beta = torch.empty((count,), dtype=torch.int64, device=self.device)
         dbit = torch.empty_like(beta)
         zeta1 = self.empty(count, nw)
         zeta2 = self.empty(count, nw)
-        arr, p = self._host_words(n, nw)
+        arr, p = self._host_n_words(n, nw)
         self._sync_stream()
         self._check(self.lib.sc_plain_bob(self.ctx, self._ptr(z), p, nw, l, count, self._ptr(beta), self._ptr(dbit),
                                           self._ptr(zeta1), self._ptr(zeta2)))
@@ -285,8 +373,17 @@ class Engine:
     def dgk_step4(self, mod: Modulus, g: int, g_inv: int, l: int, beta: torch.Tensor, beta_inv: torch.Tensor,
                   d: torch.Tensor, d_inv: torch.Tensor, alpha: torch.Tensor, alpha_tilde: torch.Tensor,
                   rsmall: torch.Tensor, delta_a: torch.Tensor) -> torch.Tensor:
-        count = d.shape[0]
-        out = torch.empty((l + 1, count, mod.nwords), dtype=torch.int32, device=self.device)
+        count = self._items(d)
+        nw = mod.nwords
+        self._arr(d, "d", count, nw)
+        self._arr(d_inv, "d_inv", count, nw)
+        self._arr(beta, "beta", l * count, nw)
+        self._arr(beta_inv, "beta_inv", l * count, nw)
+        for name, t in (("alpha", alpha), ("alpha_tilde", alpha_tilde), ("rsmall", rsmall), ("delta_a", delta_a)):
+            self._arr(t, name, dtype=torch.int64)
+            if t.numel() != count:
+                raise ValueError(f"{name}: {t.numel()} items, expected {count}")
+        out = torch.empty((l + 1, count, nw), dtype=torch.int32, device=self.device)
         self._sync_stream()
         self._check(self.lib.sc_dgk_step4(self.ctx, mod.id, self.constant(mod, g), self.constant(mod, g_inv), l,
                                           self._ptr(beta), self._ptr(beta_inv), self._ptr(d), self._ptr(d_inv),

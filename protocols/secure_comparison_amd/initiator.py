@@ -115,6 +115,9 @@ class Initiator:
             raise ValueError("Readily available DGK scheme and received DGK scheme are different.")
         pai, dgk, l = self.scheme_paillier, self.scheme_dgk, self.l_maximum_bit_length
         dev, count = x_enc.device, x_enc.shape[0]
+        nw_p, nw_d = pai.mod_n.nwords, dgk.mod_n.nwords
+        wire.expect_array(x_enc, (count, 2 * nw_p), "x_enc")
+        wire.expect_array(y_enc, (count, 2 * nw_p), "y_enc")
         if draws is None:
             pai.boot_randomness_generation_batch(count, source)
             dgk.boot_randomness_generation_batch((l + 1) * count, source)
@@ -127,14 +130,18 @@ class Initiator:
         z_enc, plain = Initiator.step_1_batch(x_enc, y_enc, l, pai, r)
         z_enc = pai.randomize_from_pool_batch(z_enc) if draws is None else pai.randomize_batch(z_enc, draws.rho_z)
         await self.communicator.send(self.other_party, wire.pack_tensor(z_enc), msg_id=f"step_1_batch_session_{sid}")
-        d_enc, beta_enc = wire.unpack_many(await self.communicator.recv(self.other_party, msg_id=f"step_4b_batch_session_{sid}"), dev)
+        d_enc, beta_enc = wire.unpack_many(await self.communicator.recv(self.other_party, msg_id=f"step_4b_batch_session_{sid}"), dev, expect=2)
+        d_enc = wire.expect_array(d_enc, (count, nw_d), "[d]")                      # sizes come from this side's l and B,
+        beta_enc = wire.expect_array(beta_enc, (l, count, nw_d), "[beta_i]")        # never from the message
         c_h = Initiator.step_4c_to_4h_batch(d_enc, beta_enc, plain, delta_a, dgk)
         c = Initiator.step_4i_batch(c_h, dgk, rhos, perm, None if draws is None else draws.r_alice_dgk)
         if draws is None:
             lp1, _, nw = c.shape
             c = dgk.randomize_from_pool_batch(c.reshape(lp1 * count, nw)).reshape(lp1, count, nw)
         await self.communicator.send(self.other_party, wire.pack_tensor(c), msg_id=f"step_4i_batch_session_{sid}")
-        zeta_1, zeta_2, delta_b_enc = wire.unpack_many(await self.communicator.recv(self.other_party, msg_id=f"step_5_batch_session_{sid}"), dev)
+        zeta_1, zeta_2, delta_b_enc = wire.unpack_many(await self.communicator.recv(self.other_party, msg_id=f"step_5_batch_session_{sid}"), dev, expect=3)
+        zeta_1, zeta_2, delta_b_enc = (wire.expect_array(t, (count, 2 * nw_p), name) for t, name in
+                                       ((zeta_1, "[[zeta_1]]"), (zeta_2, "[[zeta_2]]"), (delta_b_enc, "[[delta_B]]")))
         blta = Initiator.step_6_batch(delta_a, delta_b_enc, pai)
         return Initiator.step_7_batch(zeta_1, zeta_2, plain, l, blta, pai)
 

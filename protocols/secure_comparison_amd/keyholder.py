@@ -93,7 +93,10 @@ class KeyHolder:
         await self.communicator.send(self.other_party, wire.pack_public_schemes(pai, dgk), msg_id=f"schemes_batch_session_{sid}")
         dev = pai.engine.device
         z_enc = wire.unpack_tensor(await self.communicator.recv(self.other_party, msg_id=f"step_1_batch_session_{sid}"), dev)
-        count = z_enc.shape[0]
+        if z_enc.dim() != 2:
+            raise ValueError(f"[[z]]: received shape {tuple(z_enc.shape)}, expected [B][{2 * pai.mod_n.nwords}]")
+        count = z_enc.shape[0]                       # the batch size is Alice's to choose; everything else is checked against it
+        z_enc = wire.expect_array(z_enc, (count, 2 * pai.mod_n.nwords), "[[z]]")
         if draws is None:
             pai.boot_randomness_generation_batch(3 * count, source)
             dgk.boot_randomness_generation_batch((l + 1) * count, source)
@@ -106,6 +109,7 @@ class KeyHolder:
             d_enc, beta_enc = rnd[0].contiguous(), rnd[1:].contiguous()
         await self.communicator.send(self.other_party, wire.pack_many(d_enc, beta_enc), msg_id=f"step_4b_batch_session_{sid}")
         c_enc = wire.unpack_tensor(await self.communicator.recv(self.other_party, msg_id=f"step_4i_batch_session_{sid}"), dev)
+        c_enc = wire.expect_array(c_enc, (l + 1, count, dgk.mod_n.nwords), "[c_i]")
         delta_b = KeyHolder.step_4j_batch(c_enc, dgk)
         triple = torch.cat(KeyHolder.step_5_batch(plain, delta_b, pai), dim=0)
         if draws is None:

@@ -54,6 +54,26 @@ def set_default_engine(engine) -> None:
     _default_engine = engine
 
 
+def _fixed_point(x: Any, precision: int) -> int:
+    """round(x * 10^precision) as an exact integer: ints scale exactly, floats go through their shortest decimal
+    representation (so 0.1 with precision 1 is 1, not 0.1000000000000000055... rounded) with ties away from zero."""
+    if isinstance(x, bool):
+        x = int(x)
+    if isinstance(x, int):
+        return x * 10 ** precision
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            raise ValueError("cannot encode a non-finite plaintext")
+        from decimal import ROUND_HALF_UP, Decimal
+
+        scaled = Decimal(repr(x)).scaleb(precision)
+        q = scaled.to_integral_value(rounding=ROUND_HALF_UP)
+        if q != scaled:
+            warnings.warn(f"plaintext {x!r} has more than {precision} decimal digits: rounded to {q}e-{precision}", UserWarning)
+        return int(q)
+    return int(x) * 10 ** precision
+
+
 class _PublicKey:
     def __init__(self, **kw: int) -> None:
         self.__dict__.update(kw)
@@ -200,10 +220,16 @@ class _Scheme:
         return self.engine.download(self.engine.modinv(m, self._one(a, m.nwords)))[0]
 
     def _pow_value(self, a: int, k: int) -> int:
+        """a^k mod n for a per-ciphertext scalar k (ct * k): the exponent travels as data (sc_modexp_var), so a long-running
+        one-comparison-at-a-time service registers nothing per scalar -- only key-derived exponents are registered."""
         m = self._ct_mod
         if k < 0:
             a, k = self._inv_value(a), -k
-        return self.engine.download(self.engine.modexp_shared(m, self._one(a, m.nwords), k))[0]
+        if k == 0:
+            return 1 % m.n
+        ew = (k.bit_length() + 31) // 32
+        e = self.engine.upload([k], ew)
+        return self.engine.download(self.engine.modexp_var(m, self._one(a, m.nwords), e, 32 * ew))[0]
 
     # ---- randomness pool (boot_randomness_generation / get_randomness / shut_down of the templates package)
     def boot_randomness_generation(self, amount: int) -> None:
@@ -258,9 +284,12 @@ class Paillier(_Scheme):
     _ct_class = PaillierCiphertext
 
     def __init__(self, n: int, p: int | None = None, q: int | None = None, engine=None, use_crt: bool = True,
-                 use_pairs: bool = True) -> None:
+                 use_pairs: bool = True, precision: int = 0) -> None:
         super().__init__(engine)
         self.use_pairs = use_pairs  # exponentiations modulo N^2 / p^2 / q^2 through pair arithmetic modulo N / p / q
+        # decimal digits kept of a non-integral plaintext: x is encoded as round(x * 10^precision) ([ext] fixed-point
+        # encoding of the scheme package; perform_secure_comparison advertises `PaillierCiphertext | float`, SC/initiator.py:69-72)
+        self.precision = int(precision)
         self.public_key = _PublicKey(n=n, n_squared=n * n, g=n + 1)
         self.secret_key = None
         self.use_crt = use_crt
@@ -273,13 +302,13 @@ class Paillier(_Scheme):
         self._m_n2 = None
 
     @classmethod
-    def from_security_parameter(cls, key_length: int = 2048, engine=None, **_ignored: Any) -> "Paillier":
+    def from_security_parameter(cls, key_length: int = 2048, engine=None, precision: int = 0, **_ignored: Any) -> "Paillier":
         """Fresh key pair (SC/keyholder.py:156); prime generation runs on the host."""
         p, q = keygen.paillier_primes(key_length)
-        return cls(p * q, p, q, engine=engine)
+        return cls(p * q, p, q, engine=engine, precision=precision)
 
     def public_copy(self) -> "Paillier":
-        return Paillier(self.public_key.n, engine=self._engine)
+        return Paillier(self.public_key.n, engine=self._engine, precision=self.precision)
 
     def __eq__(self, other: object) -> bool:
         return isinstance(other, Paillier) and self.public_key.n == other.public_key.n
@@ -303,16 +332,13 @@ class Paillier(_Scheme):
     def _ct_mod(self):
         return self.mod_n2
 
-    # ---- encoding (integers only; negatives wrap mod N as in the reference's default encoding)
+    # ---- encoding: signed fixed point with `precision` decimal digits; negatives wrap mod N ([ext] default encoding)
     def _encode(self, m: Any) -> int:
-        if isinstance(m, float):
-            if not m.is_integer():
-                raise ValueError("only integral plaintexts are supported")
-            m = int(m)
-        return int(m) % self.public_key.n
+        return _fixed_point(m, self.precision) % self.public_key.n
 
-    def _decode(self, m: int) -> int:
-        return m - self.public_key.n if m > self.public_key.n // 2 else m
+    def _decode(self, m: int):
+        v = m - self.public_key.n if m > self.public_key.n // 2 else m
+        return v if self.precision == 0 else v / 10 ** self.precision
 
     # ---- batched API (device tensors [count][words])
     def encrypt_raw_batch(self, m_words: torch.Tensor) -> torch.Tensor:
@@ -461,6 +487,8 @@ class DGK(_Scheme):
         self.randomizer_bits = randomizer_bits if randomizer_bits is not None else int(2.5 * t)
         self.fixed_base_window = fixed_base_window
         self._m_n = self._m_p = self._fb_h = None
+        self._table_source: "DGK | None" = None
+        self.table_build_s = 0.0
         self._g_inv = None
         self._dec_table: dict[int, int] | None = None
 
@@ -507,15 +535,43 @@ class DGK(_Scheme):
 
     @property
     def fb_h(self):
-        """Fixed-base table for h (randomizers h^r)."""
+        """Fixed-base table for h (randomizers h^r).  Built on first use -- or taken over from the scheme object named by
+        share_tables_from (another library context on the same GPU reads the same rows)."""
         if self._fb_h is None:
-            self._fb_h = self.engine.fixed_base(self.mod_n, self.public_key.h, self.randomizer_bits, self.fixed_base_window)
+            src = self._table_source
+            if src is not None:
+                self._fb_h = self.engine.fixed_base_import(self.mod_n, src.engine, src.fb_h)
+            else:
+                import time
+
+                t0 = time.perf_counter()
+                self._fb_h = self.engine.fixed_base(self.mod_n, self.public_key.h, self.randomizer_bits, self.fixed_base_window)
+                self.engine.synchronize()
+                self.table_build_s += time.perf_counter() - t0
         return self._fb_h
+
+    def share_tables_from(self, other: "DGK") -> None:
+        """Read `other`'s device-resident fixed-base tables instead of building copies (same key, window and randomizer
+        width; `other` may be bound to another engine of the same GPU -- the concurrent shards of batch.ConcurrentShards)."""
+        if other.public_key != self.public_key or other.fixed_base_window != self.fixed_base_window or \
+                other.randomizer_bits != self.randomizer_bits or (other.secret_key is None) != (self.secret_key is None):
+            raise ValueError("tables can only be shared between scheme objects of the same key and table parameters")
+        self._table_source = other
+
+    def table_bytes(self) -> int:
+        """Device bytes of the fixed-base tables this object has built or taken over so far."""
+        e = self.engine
+        total = e.fixed_base_bytes(self._fb_h) if self._fb_h is not None else 0
+        for name in ("p", "q"):
+            k = (getattr(self, "_crt", None) or {}).get(name)
+            if k:
+                total += e.fixed_base_bytes(k["fb"])
+        return total
 
     def _encode(self, m: Any) -> int:
         if isinstance(m, float):
             if not m.is_integer():
-                raise ValueError("only integral plaintexts are supported")
+                raise ValueError("DGK plaintexts are integers modulo u")
             m = int(m)
         return int(m)
 
@@ -547,11 +603,20 @@ class DGK(_Scheme):
     def _crt_setup(self):
         if getattr(self, "_crt", None) is None:
             e, sk, pk = self.engine, self.secret_key, self.public_key
+            import time
+
             crt = {}
+            src = self._table_source
             for name, prime, v in (("p", sk.p, sk.v_p), ("q", sk.q, sk.v_q)):
                 m = e.modulus(prime)
-                crt[name] = {"m": m, "m_v": e.modulus(v),
-                             "fb": e.fixed_base(m, pk.h % prime, v.bit_length(), min(self.fixed_base_window, 16))}
+                if src is not None:
+                    fb = e.fixed_base_import(m, src.engine, src._crt_setup()[name]["fb"])
+                else:
+                    t0 = time.perf_counter()
+                    fb = e.fixed_base(m, pk.h % prime, v.bit_length(), min(self.fixed_base_window, 16))
+                    e.synchronize()
+                    self.table_build_s += time.perf_counter() - t0
+                crt[name] = {"m": m, "m_v": e.modulus(v), "fb": fb}
             self._crt = crt
         return self._crt
 

@@ -1,0 +1,177 @@
+"""GPU tests added in round 2: the per-GPU shares of BASELINE configs[3] / configs[4] at full size, the exact
+non-invertible index, shared fixed-base tables, one context alternating between streams, and bench.py's rank handling."""
+import json
+import os
+import random
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT, oracle_dgk, oracle_paillier
+from oracle import sc_oracle as o
+from test_gpu_parity import _draw_tensors, _schemes
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_rows(engine, idx, l, sk, dgk, x_enc, y_enc, draws):
+    """oracle.compare on rows `idx` of a device-resident batch (inputs and every random draw downloaded)."""
+    it = torch.tensor(idx, device=engine.device)
+    ints = lambda t: engine.download(t[it])                                  # noqa: E731
+    perb = lambda t: [engine.download(t[:, i]) for i in idx]                 # noqa: E731
+    M = (1 << 64) - 1
+    perms = [None] * len(idx) if draws.permutation is None else draws.permutation[it].tolist()
+    rows = zip(ints(x_enc), ints(y_enc), ints(draws.r), [int(v) & M for v in draws.delta_a[it].tolist()], perb(draws.rhos),
+               ints(draws.rho_z), perb(draws.r_bob_dgk), perb(draws.r_alice_dgk), ints(draws.rho_zeta_1), ints(draws.rho_zeta_2),
+               ints(draws.rho_delta_b), perms)
+    expect = []
+    for xe, ye, r, da, rhos, rho_z, rb, rc, z1, z2, zb, pm in rows:
+        if pm is not None:       # the library randomizes c_j with r_alice[j] before the shuffle, the oracle output k after it
+            rc = [rc[src] for src in pm]
+        dr = o.Draws(r=r, delta_a=da, rhos=rhos, perm=pm, rho_z=rho_z, r_d=rb[0], r_beta=rb[1:], r_c=rc, rho_zeta1=z1,
+                     rho_zeta2=z2, rho_delta_b=zb)
+        expect.append(o.compare(xe, ye, l, sk, dgk, dr, True))
+    return expect
+
+
+@pytest.mark.parametrize("pbits, dname, B, l", [
+    (2048, "dgk_2048_l32", 131072, 32),      # configs[3]: 1M comparisons over 8 GPUs -> 131072 per GPU
+    (3072, "dgk_2048_l64", 32768, 64),       # configs[4]: 262144 over 8 GPUs -> 32768 per GPU; DGK size unspecified there:
+    (3072, "dgk_3072_l64", 32768, 64),       #             2048-bit (the reference's default, SC/keyholder.py:140) and 3072-bit
+])
+def test_per_gpu_shares_of_the_eight_gpu_configs_full_size(engine, keys, pbits, dname, B, l):
+    """Full-size per-GPU shares (scratch arena, parking buffer, inversion-tree depth, 67-bit rho at l = 64): Dec(result) ==
+    [x <= y] for every comparison, and a sampled subset -- first, last, one in the last partially filled wave of every kernel
+    configuration -- bit-exact against the oracle, shuffle included."""
+    import bench
+    from protocols.secure_comparison_amd.batch import secure_comparison_batch
+
+    sk, dgk = oracle_paillier(keys, pbits), oracle_dgk(keys, dname)
+    engine.set_latency_mode(1)
+    try:
+        alice_p, alice_d, bob_p, bob_d = _schemes(engine, sk, dgk, 400)
+        x, y, x_enc, y_enc, draws = bench.synth_inputs(engine, l, alice_p, bob_p, bob_d, B, 400, seed=l + pbits, shuffle=True)
+        res = secure_comparison_batch(x_enc, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws)
+        dec = bob_p.decrypt_raw_batch(res)
+        assert bool(((dec[:, 0] == (x <= y).to(torch.int32)) & (dec[:, 1:] == 0).all(dim=1)).all().item())
+        idx = [0, 1, 8, 9, B // 2 + 3, B - 67, B - 2, B - 1]
+        assert engine.download(res[torch.tensor(idx, device=engine.device)]) == _oracle_rows(engine, idx, l, sk, dgk, x_enc, y_enc, draws)
+    finally:
+        engine.set_latency_mode(0)
+
+
+def test_not_invertible_index_is_exact(engine):
+    """sc_modinv names a non-invertible element itself (not the chunk it sits in), at every depth of the inversion tree."""
+    from protocols.secure_comparison_amd.engine import NotInvertibleError
+
+    rng = random.Random(5)
+    n = 3 * 5 * 7 * (rng.getrandbits(1000) | 1)
+    mod = engine.modulus(n)
+    import math
+
+    def units(k):
+        out = []
+        while len(out) < k:
+            v = rng.randrange(2, n)
+            if math.gcd(v, n) == 1:
+                out.append(v)
+        return out
+
+    for count, bad_at in ((3, 1), (48, 47), (49, 0), (500, 333), (5000, 4999), (70000, 12345)):
+        xs = units(min(count, 600))
+        xs = (xs * (count // len(xs) + 1))[:count]
+        xs[bad_at] = 35 * xs[bad_at]
+        with pytest.raises(NotInvertibleError) as ei:
+            engine.modinv(mod, engine.upload(xs, mod.nwords))
+        assert ei.value.index == bad_at and str(bad_at) in str(ei.value)
+    # two bad elements: one of them is named
+    xs = units(300)
+    xs[17] *= 3
+    xs[250] *= 7
+    with pytest.raises(NotInvertibleError) as ei:
+        engine.modinv(mod, engine.upload(xs, mod.nwords))
+    assert ei.value.index in (17, 250)
+    # and a clean batch still inverts
+    xs = units(300)
+    assert engine.download(engine.modinv(mod, engine.upload(xs, mod.nwords))) == [pow(v, -1, n) for v in xs]
+
+
+def test_shared_fixed_base_tables(engine, keys):
+    """A second library context imports the first one's tables (sc_fbt_import): same residues, no second copy, and the rows
+    outlive the context that built them."""
+    from protocols.secure_comparison_amd import DGK
+    from protocols.secure_comparison_amd.engine import Engine
+
+    dgk = oracle_dgk(keys, "dgk_1024_l16")
+    rng = random.Random(8)
+    e1, e2 = Engine(), Engine()
+    mk = lambda e: DGK(dgk.n, dgk.g, dgk.h, dgk.u, dgk.t, dgk.p, dgk.q, dgk.v_p, dgk.v_q, engine=e, randomizer_bits=400, fixed_base_window=8)  # noqa: E731
+    bob1, bob2 = mk(e1), mk(e2)
+    alice1, alice2 = bob1.public_copy(), bob2.public_copy()
+    bob2.share_tables_from(bob1)
+    alice2.share_tables_from(alice1)
+    rs = [rng.getrandbits(400) for _ in range(50)]
+    cs = [dgk.enc_raw(rng.randrange(dgk.u)) for _ in rs]
+    expect = [dgk.randomize(c, r) for c, r in zip(cs, rs)]
+    for sch in (alice1, alice2, bob1, bob2):
+        e = sch.engine
+        assert e.download(sch.randomize_batch(e.upload(cs, sch.mod_n.nwords), e.upload(rs, 13))) == expect
+    assert alice2.table_build_s == 0.0 and bob2.table_build_s == 0.0 and alice1.table_build_s > 0.0
+    assert alice2.table_bytes() == alice1.table_bytes() > 0 and bob2.table_bytes() == bob1.table_bytes() > 0
+    assert bob1._fb_h is None                      # the key holder's CRT path never builds the table for h mod n
+    e1.close()                                     # the builder goes away; the importer keeps the rows alive
+    assert e2.download(alice2.randomize_batch(e2.upload(cs, alice2.mod_n.nwords), e2.upload(rs, 13))) == expect
+    other = DGK(dgk.n, dgk.g, dgk.h, dgk.u, dgk.t, engine=e2, randomizer_bits=300, fixed_base_window=8)
+    with pytest.raises(ValueError):
+        other.share_tables_from(alice2)
+    e2.close()
+
+
+def test_one_context_alternating_between_streams(keys):
+    """Engine follows torch's current stream; the context's scratch arena / temporaries / parked tables are reused from call
+    to call, so sc_ctx_set_stream must order the previous stream's work before the next stream's (regression for silently
+    wrong residues when a scheme object is used under `with torch.cuda.stream(s)` for some calls only)."""
+    from protocols.secure_comparison_amd import DGK, Paillier
+    from protocols.secure_comparison_amd.engine import Engine
+
+    sk, dgk = oracle_paillier(keys, 2048), oracle_dgk(keys, "dgk_2048_l32")
+    eng = Engine()
+    eng.set_latency_mode(0)
+    pai = Paillier(sk.n, sk.p, sk.q, engine=eng)
+    alice = pai.public_copy()
+    rng = random.Random(12)
+    B = 3000                                           # long enough launches that an unordered successor would overlap
+    rho = eng.upload([1 + rng.randrange(sk.n - 1) for _ in range(B)], alice.mod_n.nwords)
+    ms = [rng.randrange(sk.n) for _ in range(B)]
+    c = alice.encrypt_raw_batch(eng.upload(ms, alice.mod_n.nwords))
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for k in range(6):                                 # randomize on one stream, decrypt right away on another: both use the
+        with torch.cuda.stream(s1 if k % 2 == 0 else s2):   # same scratch arena and temporaries
+            r = alice.randomize_batch(c, rho)
+        with torch.cuda.stream(s2 if k % 2 == 0 else s1):
+            s = torch.cuda.current_stream()
+            s.wait_stream(s1 if k % 2 == 0 else s2)    # the caller's own buffers follow the usual stream rules
+            outs.append(pai.decrypt_raw_batch(r))
+    torch.cuda.synchronize()
+    for d in outs:
+        assert eng.download(d) == ms
+    eng.close()
+
+
+def test_bench_rank_handling_on_one_gpu():
+    """`bench.py --gpus 1 --force-dist` goes through RCCL with one rank and says so; `--gpus 2` on a one-GPU box fails."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    bench = os.path.join(ROOT, "bench.py")
+    cp = subprocess.run([sys.executable, bench, "--gpus", "1", "--force-dist", "--batch", "512", "--l", "16", "--dgk", "dgk_2048_l16", "--fb-window", "8",
+                         "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=600)
+    assert cp.returncode == 0, cp.stderr[-2000:]
+    line = json.loads(cp.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and line["rank_devices"] == [0] and line["value"] > 0
+    assert 0 < line["roofline"]["frac"] < 1 and line["config"]["fixed_base_table_bytes"] > 0
+    if torch.cuda.device_count() < 2:
+        cp = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+        assert cp.returncode != 0 and "n_gpus" not in cp.stdout

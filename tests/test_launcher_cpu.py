@@ -1,0 +1,75 @@
+"""The N > 1 launch path on the CPU: `bench.py --gpus N` starts its ranks through
+protocols.secure_comparison_amd.launcher, refuses rank counts it cannot honour, and never prints a one-rank line for an
+N-rank request."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+WORKER = os.path.join(ROOT, "tests", "_launch_worker.py")
+
+
+def _clean_env():
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+@pytest.mark.parametrize("B", [6, 5])  # even and ragged shards
+def test_spawned_ranks_form_one_group(tmp_path, B, monkeypatch):
+    from protocols.secure_comparison_amd import launcher
+
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    out = tmp_path / "r.json"
+    rc = launcher.spawn_ranks(WORKER, [str(out), "2", str(B)], 2, need_gpus=False)
+    assert rc == 0
+    got = json.load(open(out))
+    assert got == {"ranks_seen": 2, "world": 2, "equal": True, "decrypts": True}
+
+
+def test_failing_rank_fails_the_job(tmp_path, monkeypatch):
+    from protocols.secure_comparison_amd import launcher
+
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    rc = launcher.spawn_ranks(WORKER, [str(tmp_path / "r.json"), "2", "4", "1"], 2, need_gpus=False)
+    assert rc != 0 and not (tmp_path / "r.json").exists()
+
+
+def test_world_size_must_match_the_request(monkeypatch):
+    from protocols.secure_comparison_amd import launcher
+
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    with pytest.raises(SystemExit):
+        launcher.expect_world(8)
+    assert launcher.expect_world(1) == (0, 0, 1)
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setenv("RANK", "3")
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    assert launcher.expect_world(4) == (3, 3, 4)
+    monkeypatch.delenv("WORLD_SIZE")
+    assert launcher.rank_env() is None and launcher.expect_world(1) == (0, 0, 1)
+
+
+def test_bench_refuses_rank_counts_it_cannot_honour():
+    """No GPU in the CPU tier: `--gpus 2` must fail before anything runs (here: this node shows fewer than 2 GPUs), and under
+    a launcher whose WORLD_SIZE differs from --gpus it must fail too -- never a silent n_gpus: 1 line."""
+    import torch
+
+    bench = os.path.join(ROOT, "bench.py")
+    if torch.cuda.device_count() < 2:
+        cp = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=_clean_env(), capture_output=True,
+                            text=True, timeout=300)
+        assert cp.returncode != 0 and "GPU" in cp.stderr and "n_gpus" not in cp.stdout
+    env = _clean_env()
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    cp = subprocess.run([sys.executable, bench, "--gpus", "8", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True,
+                        timeout=300)
+    assert cp.returncode != 0 and "WORLD_SIZE" in cp.stderr and "n_gpus" not in cp.stdout

@@ -1,0 +1,196 @@
+"""Everything a peer or a caller can get wrong at the edges of the batch path is refused with ValueError before a kernel
+sees a pointer: malformed wire messages, arrays of the wrong dtype / shape / device, and the plaintext encodings the
+reference's signature advertises (SC/initiator.py:69-72: `PaillierCiphertext | float`)."""
+import asyncio
+import random
+import struct
+import warnings
+
+import pytest
+import torch
+
+from _comm import DictionaryCommunicator
+from _oracle_engine import OracleEngine
+from conftest import oracle_dgk, oracle_paillier
+from oracle import sc_oracle as o
+from protocols.secure_comparison_amd import DGK, Initiator, KeyHolder, Paillier, wire
+
+L = 16
+
+
+@pytest.fixture(scope="module")
+def world(keys):
+    osk, od = oracle_paillier(keys, 1024), oracle_dgk(keys, "dgk_tiny_l16")
+    eng = OracleEngine()
+    bob_p = Paillier(osk.n, osk.p, osk.q, engine=eng)
+    bob_d = DGK(od.n, od.g, od.h, od.u, od.t, od.p, od.q, od.v_p, od.v_q, full_decryption=True, engine=eng, randomizer_bits=50)
+    return osk, od, eng, bob_p, bob_d
+
+
+def test_wire_header_is_checked_against_the_payload():
+    t = torch.arange(24, dtype=torch.int32).reshape(2, 3, 4)
+    buf = wire.pack_tensor(t)
+    assert torch.equal(wire.unpack_tensor(buf), t)
+    bad_dims = buf[:8] + struct.pack("<3Q", 2, 3, 400) + buf[32:]          # announces more items than it carries
+    bad_code = buf[:4] + struct.pack("<BBH", 9, 3, 0) + buf[8:]            # unknown dtype code
+    bad_ndim = buf[:4] + struct.pack("<BBH", 0, 200, 0) + buf[8:]          # absurd rank
+    for bad in (bad_dims, bad_code, bad_ndim, buf[:-4], buf[:6], b""):
+        with pytest.raises(ValueError):
+            wire.unpack_tensor(bad)
+    many = wire.pack_many(t, t)
+    assert len(wire.unpack_many(many, expect=2)) == 2
+    for bad in (many[:-1], many[:10], struct.pack("<I", 3) + many[4:]):
+        with pytest.raises(ValueError):
+            wire.unpack_many(bad)
+    with pytest.raises(ValueError):
+        wire.unpack_many(many, expect=3)
+    with pytest.raises(ValueError):
+        wire.expect_array(t, (2, 3, 5), "t")
+    with pytest.raises(ValueError):
+        wire.expect_array(t.to(torch.int64), (2, 3, 4), "t")
+
+
+class _Tamper(DictionaryCommunicator):
+    """Replaces the message with label `target` by `forge(original)` on its way to the receiver."""
+
+    def __init__(self, box, target, forge):
+        super().__init__(box)
+        self.target, self.forge = target, forge
+
+    async def recv(self, party_id, msg_id):
+        msg = await super().recv(party_id, msg_id)
+        return self.forge(msg) if msg_id.startswith(self.target) else msg
+
+
+def _run_pair(world, alice_comm, bob_comm, B=3):
+    osk, od, eng, bob_p, bob_d = world
+    rng = random.Random(3)
+    nw = bob_p.mod_n.nwords
+    tx = eng.upload([osk.enc_raw(rng.randrange(1 << L)) for _ in range(B)], 2 * nw)
+    ty = eng.upload([osk.enc_raw(rng.randrange(1 << L)) for _ in range(B)], 2 * nw)
+    alice = Initiator(L, alice_comm, "bob")
+    bob = KeyHolder(L, bob_comm, "alice", bob_p, bob_d)
+
+    async def go():
+        # a refused message leaves the other player waiting: run Alice and Bob as tasks and cancel the survivor
+        ta = asyncio.ensure_future(alice.perform_secure_comparison_batch(tx, ty, None, engine=eng))
+        tb = asyncio.ensure_future(bob.perform_secure_comparison_batch(None))
+        done, pending = await asyncio.wait({ta, tb}, return_when=asyncio.FIRST_EXCEPTION)
+        for t in pending:
+            t.cancel()
+        for t in done:
+            t.result()
+        return ta.result()
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return asyncio.run(go())
+
+
+@pytest.mark.parametrize("target, forge", [
+    # Bob -> Alice: [d], [beta_i].  A peer announcing another l or another batch size must not steer Alice's kernels.
+    ("step_4b_batch", lambda m: wire.pack_many(*[t[..., :-1].contiguous() for t in wire.unpack_many(m)])),          # narrower residues
+    ("step_4b_batch", lambda m: wire.pack_many(wire.unpack_many(m)[0], wire.unpack_many(m)[1][:-1].contiguous())),   # l - 1 planes
+    ("step_4b_batch", lambda m: wire.pack_many(wire.unpack_many(m)[0], wire.unpack_many(m)[1].to(torch.uint8))),     # byte array
+    ("step_4b_batch", lambda m: wire.pack_many(wire.unpack_many(m)[0][:-1].contiguous(), wire.unpack_many(m)[1])),   # B - 1 items
+    ("step_4b_batch", lambda m: wire.pack_many(wire.unpack_many(m)[0])),                                             # one array missing
+    ("step_5_batch", lambda m: wire.pack_many(*[t.reshape(-1) for t in wire.unpack_many(m)])),                      # flattened
+    ("step_5_batch", lambda m: wire.pack_many(*[t.to(torch.int64) for t in wire.unpack_many(m)])),
+])
+def test_alice_refuses_malformed_batches(world, target, forge):
+    box = {}
+    with pytest.raises(ValueError):
+        _run_pair(world, _Tamper(box, target, forge), DictionaryCommunicator(box))
+
+
+@pytest.mark.parametrize("target, forge", [
+    ("step_1_batch", lambda m: wire.pack_tensor(wire.unpack_tensor(m)[:, :-1].contiguous())),
+    ("step_1_batch", lambda m: wire.pack_tensor(wire.unpack_tensor(m).reshape(-1))),
+    ("step_1_batch", lambda m: wire.pack_tensor(wire.unpack_tensor(m).to(torch.uint8))),
+    ("step_4i_batch", lambda m: wire.pack_tensor(wire.unpack_tensor(m)[1:].contiguous())),                            # l planes instead of l + 1
+    ("step_4i_batch", lambda m: wire.pack_tensor(wire.unpack_tensor(m)[:, :-1].contiguous())),                        # B - 1 comparisons
+    ("step_4i_batch", lambda m: wire.pack_tensor(wire.unpack_tensor(m).to(torch.int64))),
+])
+def test_bob_refuses_malformed_batches(world, target, forge):
+    box = {}
+    with pytest.raises(ValueError):
+        _run_pair(world, DictionaryCommunicator(box), _Tamper(box, target, forge))
+
+
+def test_untampered_pair_still_runs(world):
+    osk = world[0]
+    box = {}
+    res = _run_pair(world, DictionaryCommunicator(box), DictionaryCommunicator(box))
+    assert all(osk.dec_raw(v) in (0, 1) for v in world[2].download(res))
+
+
+def test_engine_array_checks_run_before_any_pointer_is_taken():
+    """Engine._arr is what every C-ABI wrapper passes its arrays through; it needs no GPU to say no."""
+    from protocols.secure_comparison_amd.engine import Engine
+
+    e = object.__new__(Engine)
+    e.device = torch.device("cpu")
+    good = torch.zeros((4, 8), dtype=torch.int32)
+    assert e._arr(good, "x", 4, 8) is good and e._arr(None, "x", optional=True) is None
+    assert e._arr(torch.zeros(8, dtype=torch.int32), "x", 4, 8, broadcast=True) is not None
+    cases = [(good.to(torch.uint8), 4, 8), (good.to(torch.int64), 4, 8), (good[:, ::2], 4, 4), (good, 5, 8), (good, 4, 7),
+             (good.reshape(-1), 4, 8), (torch.tensor(3, dtype=torch.int32), None, None), ([1, 2, 3], None, None), (None, None, None)]
+    for t, rows, words in cases:
+        with pytest.raises(ValueError):
+            e._arr(t, "x", rows, words)
+    e.device = torch.device("meta")
+    with pytest.raises(ValueError):
+        e._arr(good, "x", 4, 8)
+
+
+def test_plaintext_encodings(world):
+    """Integral floats and fixed-point floats at the unsafe_encrypt edge (the reference takes `PaillierCiphertext | float`
+    and encodes with the scheme's precision, SC/initiator.py:93-102); DGK plaintexts stay integers."""
+    osk, od, eng, bob_p, bob_d = world
+    assert bob_p.unsafe_encrypt(42.0).value == osk.enc_raw(42) and bob_p.decrypt(bob_p.unsafe_encrypt(-7.0)) == -7
+    assert isinstance(bob_p.decrypt(bob_p.unsafe_encrypt(5)), int)
+    fx = Paillier(osk.n, osk.p, osk.q, engine=eng, precision=3)
+    assert fx.unsafe_encrypt(1.5).value == osk.enc_raw(1500) and fx.unsafe_encrypt(-0.001).value == osk.enc_raw(osk.n - 1)
+    assert fx.unsafe_encrypt(0.1).value == osk.enc_raw(100) and fx.unsafe_encrypt(2).value == osk.enc_raw(2000)
+    assert fx.decrypt(fx.unsafe_encrypt(-2.25)) == -2.25 and fx.decrypt(fx.unsafe_encrypt(3), apply_encoding=False) == 3000
+    assert fx.public_copy().precision == 3
+    with pytest.warns(UserWarning, match="decimal digits"):
+        assert fx.unsafe_encrypt(0.12345).value == osk.enc_raw(123)
+    with pytest.warns(UserWarning, match="decimal digits"):
+        assert bob_p.unsafe_encrypt(2.5).value == osk.enc_raw(3)            # precision 0: ties away from zero
+    for bad in (float("nan"), float("inf")):
+        with pytest.raises(ValueError):
+            bob_p.unsafe_encrypt(bad)
+    assert bob_d.unsafe_encrypt(3.0).value == od.enc_raw(3)
+    with pytest.raises(ValueError):
+        bob_d.unsafe_encrypt(0.5)
+    # two fixed-point values through the whole single-comparison protocol
+    box = {}
+    alice = Initiator(L, DictionaryCommunicator(box), "bob")
+    bob = KeyHolder(L, DictionaryCommunicator(box), "alice", fx, bob_d)
+
+    async def go():
+        res, _ = await asyncio.gather(alice.perform_secure_comparison(1.25, 1.3), bob.perform_secure_comparison())
+        return res
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert fx.decrypt(asyncio.run(go()), apply_encoding=False) == 1
+
+
+def test_scalar_multiplication_registers_nothing(world):
+    """ct * k sends k as data (modexp_var): the engine's exponent registry does not grow with the scalars used."""
+    osk, od, eng, bob_p, bob_d = world
+    calls = []
+    orig = eng.modexp_shared
+    eng.modexp_shared = lambda *a, **k: (calls.append(a), orig(*a, **k))[1]
+    try:
+        c = bob_d.unsafe_encrypt(5)
+        rng = random.Random(1)
+        for _ in range(5):
+            k = 1 + rng.randrange(od.u - 1)
+            assert (c * k).value == od.mul(c.value, k)
+        assert (bob_p.unsafe_encrypt(3) * 12345).value == osk.mul(osk.enc_raw(3), 12345) and (c * 0).value == 1
+    finally:
+        eng.modexp_shared = orig
+    assert not calls
