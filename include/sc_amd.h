@@ -53,6 +53,12 @@ int sc_abi_version(void);
  * arrays in memory): twice the waves, 1.8x shorter dependent chains, lower multiply-add density.  mode 0: never; 1 (default):
  * when the L = 18 launch would leave at least half of the SIMDs without a wave; 2: whenever such a kernel exists (tests). */
 int sc_ctx_set_latency_mode(sc_ctx* ctx, int mode);
+/* Large-batch policy for moduli of at most 1028 bits (the primes p, q of 2048-bit keys: key-holder CRT, DGK zero test).  The
+ * shared-exponent entry points sc_modexp_shared and sc_modexp_shared_isone can run such a modulus in the one-lane
+ * configuration -- one number per lane, 37 limbs of 28 bits, operands of a squaring in registers, modulus in scalar
+ * registers: 1.25x the rate per number, but 64 numbers per wave (exponents of more than 64 bits only).  mode 0: never; 1 (default): from one and a half rounds of the
+ * chip's resident waves (196608 numbers on 256 CUs); 2: whenever the modulus fits (tests).  Results are the same canonical residues in every mode. */
+int sc_ctx_set_onelane_mode(sc_ctx* ctx, int mode);
 
 /* device memory helpers for callers that do not bring their own allocator */
 int sc_malloc(sc_ctx* ctx, size_t bytes, void** out_dptr);

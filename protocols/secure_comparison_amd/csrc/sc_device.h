@@ -59,7 +59,7 @@ struct Grp {
   static constexpr int W = W_;                          // bits per limb: 2L products of 2W bits must fit 64 bits
   static constexpr uint32_t LMASK = (1u << W_) - 1;
   static_assert(2 * W_ + 6 <= 64 && (2 * L_ + 2) <= (1 << (64 - 2 * W_ - 1)) * 2, "column accumulators would overflow");
-  static constexpr int SP = S + 3;                      // padded limb-array stride in LDS (odd)
+  static constexpr int SP = (S + 3) | 1;                // padded limb-array stride in LDS (odd: conflict-free across groups)
   static constexpr int WP = (W * S + 31) / 32 + 2;      // 32-bit-word scratch stride in LDS
   int lane, g, j;                                       // lane in wave, group in wave, lane in group
   uint32_t notTop, notBot;                              // 0 for the top / bottom lane of the group
@@ -79,7 +79,12 @@ struct Grp {
     asm volatile("" : "+v"(m));
     lmask_v = m;
 #pragma unroll
-    for (int l = 0; l < L; l++) n[l] = n_limbs[j * L + l];
+    for (int l = 0; l < L; l++) {
+      n[l] = n_limbs[j * L + l];
+      // one-lane numbers: every lane holds the same modulus limbs -- pin them in scalar registers (a v_mad_u64_u32 takes one
+      // scalar operand), which frees L vector registers; the compiler cannot prove the load uniform and read-only by itself
+      if constexpr (G == 1) n[l] = __builtin_amdgcn_readfirstlane(n[l]);
+    }
   }
 
   __device__ __forceinline__ uint32_t from_above(uint32_t v) const {
@@ -168,6 +173,52 @@ struct Grp {
       const uint64_t v = (uint64_t)r[0] + (((uint64_t)chi << 32) | clo);
       r[0] = (uint32_t)v & LMASK;
       r[1] += (uint32_t)(v >> W);
+    }
+  }
+  // -------------------------------------------------------------------------------------------
+  // G == 1 ("one lane per number"): the whole number lives in this lane, so a product needs no LDS staging, no cross-lane
+  // move and no quotient broadcast, and the modulus limbs are wave-uniform (the compiler keeps them in scalar registers).
+  // Per limb step 2L multiply-adds + 4 other instructions, paid by ONE lane per number -- the G-lane form pays its per-step
+  // bookkeeping in every lane of the group (G S steps per number instead of S).
+  //   MODE 0: r = a * b / R.  MODE 3: r = b * b / R (a ignored).  DOUBLE_A: the multiplier is 2 a (second pass of a pair
+  //   squaring: 2 x0 x1).  COLLECT / INIT / ADDN as in mont().  r may alias a or b (written after the last read).
+  // Column bound: L reduction products plus L (possibly doubled) operand products per column: 3 L 2^(2W) <= 2^64 holds
+  // for (L, W) = (37, 28) and (18, 29).
+  // -------------------------------------------------------------------------------------------
+  template <int MODE, bool COLLECT = false, bool INIT = false, bool ADDN = false, bool DOUBLE_A = false>
+  __device__ __forceinline__ void mont_r(uint32_t (&r)[L], const uint32_t (&a)[L], const uint32_t (&b)[L], uint32_t (&quot)[L],
+                                         const uint32_t (&init)[L]) const {
+    static_assert(G == 1, "register-operand products exist for one-lane numbers only");
+    static_assert((uint64_t)3 * L <= ((uint64_t)1 << (64 - 2 * W)), "column accumulators would overflow");   // L q n products + L doubled ones
+    uint64_t T[L];
+#pragma unroll
+    for (int i = 0; i < L; i++) T[i] = INIT ? (uint64_t)init[i] : 0ull;
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+      if constexpr (MODE == 0) {
+        const uint32_t ai = DOUBLE_A ? (a[l] << 1) : a[l];
+#pragma unroll
+        for (int c = 0; c < L; c++) T[(l + c) % L] += (uint64_t)ai * b[c];
+      }
+      if constexpr (MODE == 3) {
+        const uint32_t ai = b[l], ai2 = b[l] << 1;
+        T[(l + l) % L] += (uint64_t)ai * b[l];
+#pragma unroll
+        for (int c = l + 1; c < L; c++) T[(l + c) % L] += (uint64_t)ai2 * b[c];
+      }
+      const uint32_t q = ((uint32_t)T[l] * n0inv) & LMASK;
+      if constexpr (COLLECT) quot[l] = q;
+#pragma unroll
+      for (int c = 0; c < L; c++) T[(l + c) % L] += (uint64_t)q * n[c];
+      T[(l + 1) % L] += T[l] >> W;     // column 0 is now divisible by 2^W: only its carry survives
+      T[l] = 0;                        // and the register becomes the new top column
+    }
+    uint64_t c = ADDN ? (uint64_t)(n[0] - 1u) : 0ull;   // n is odd: limb 0 is >= 1
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+      const uint64_t v = T[l] + c + ((ADDN && l > 0) ? (uint64_t)n[l] : 0ull);
+      r[l] = (uint32_t)v & LMASK;
+      c = v >> W;
     }
   }
   // One local carry pass plus the hand-over of the lane carry: brings limbs that grew by lazy additions (entries
@@ -296,6 +347,139 @@ struct Grp {
       pair_fix(x1);
     }
   }
+  // ---- one-lane forms (G == 1) of the pair operations.  Register budget: x0, x1, the quotient digits and the 2L column
+  // registers are 5 L = 185 registers; anything else that must survive a pass is parked (in the lane's LDS staging area, free
+  // during a squaring; in a spare row of the slot's scratch table during a product) instead of spilled by the compiler.
+  // (x0, x1) <- (x0, x1)^2 with both operands in registers: t = x0^2 with its quotient digits, then
+  // x1 <- (2 x0 x1 + R - q + q' n) / R + n - 1 with the multiplier doubled on the fly.  `park`: L words of LDS (this lane's).
+  __device__ __forceinline__ void pair_sqr_r(uint32_t (&x0)[L], uint32_t (&x1)[L], uint32_t* park) const {
+    // x1 is idle during the first pass and t during the second: each waits its turn in `park`, so that at most x0, one of
+    // them, the quotient digits and the columns are in registers at any time (4 L + misc instead of 6 L)
+    uint32_t q[L];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int l = 0; l < L; l++) park[l] = x1[l];
+    {
+      uint32_t t[L];
+      mont_r<3, true>(t, x0, x0, q, q);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int l = 0; l < L; l++) { x1[l] = park[l]; }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int l = 0; l < L; l++) { park[l] = t[l]; }
+    }
+    neg_quot_init(q);
+    mont_r<0, false, true, true, true>(x1, x0, x1, q, q);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int l = 0; l < L; l++) x0[l] = park[l];
+  }
+  // (x0, x1) <- (x0, x1) * (y0, y1) with ONE staging area in LDS (a second one would cost the eighth wave per CU): three
+  // passes t = x0 y0 (quotient recorded), v = x1 y0 (same staged operand), u = x0 y1 + R - q, then (x0, x1) <- (t, u + v + n - 1):
+  // 6 S^2 multiply-adds.  y0_src / y1_src: limb arrays of this lane's operand, element stride YS (rows of the slot's table, or LDS
+  // constants).  The three passes are ONE rolled loop over a single instance of the product code (the unrolled 37-limb product
+  // is 29 KB of code), the operand is always x0 (x0 and x1 trade places around the second pass) and t waits in `t_park`
+  // (L elements of stride TS in the slot's table).
+  template <int TS>
+  __device__ __forceinline__ void pair_mul_seq(uint32_t (&x0)[L], uint32_t (&x1)[L], const uint32_t* y0_src, const uint32_t* y1_src, int ys,
+                                               uint32_t* area, uint32_t* t_park) const {
+    static_assert(G == 1, "sequential pair product: one-lane configurations only");
+    uint32_t q[L];
+#pragma unroll
+    for (int l = 0; l < L; l++) q[l] = 0;
+#pragma unroll 1
+    for (int pass = 0; pass < 3; pass++) {
+      if (pass != 1) {
+        const uint32_t* src = (pass == 0) ? y0_src : y1_src;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int l = 0; l < L; l++) area[l] = src[l * ys];
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (pass != 0) {
+#pragma unroll
+        for (int l = 0; l < L; l++) { const uint32_t v = x0[l]; x0[l] = x1[l]; x1[l] = v; }
+      }
+      uint32_t r[L];
+      mont_a1(r, area, x0, q, pass == 2, pass == 0);
+      if (pass == 0) {
+#pragma unroll
+        for (int l = 0; l < L; l++) t_park[l * TS] = r[l];
+        neg_quot_init(q);
+      } else if (pass == 1) {
+#pragma unroll
+        for (int l = 0; l < L; l++) x0[l] = r[l];                        // v replaces the dead operand (old x1)
+      } else {
+#pragma unroll
+        for (int l = 0; l < L; l++) x1[l] += r[l];                       // the x1 slot held v after the second exchange
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < L; l++) x0[l] = t_park[l * TS];
+    pair_fix(x1);
+  }
+  // Product pass with the multiplier in this lane's LDS area: r = (a b + start + q n) / R, start = q_io when `use_init` else
+  // 0; the quotient digits replace q_io when `collect`, otherwise q_io is left alone (both flags wave-uniform run-time values).
+  // Code size matters here: next to the register-operand squaring passes (45 KB) a fully unrolled 37-limb product (29 KB) no
+  // longer fits the 64 KB instruction cache two CUs share, and every pair product would stream its code from L2 (measured:
+  // 2x the time of the products).  So the limb steps run in CHUNKS: CH steps unrolled (the column registers rotate by
+  // renaming inside a chunk), then the columns -- and the quotient digits, kept as a shift register -- are physically rotated
+  // by CH positions so that the next chunk can run the same code: 4 chunks of 8 steps and one of 5 (37 is prime), 8 KB of
+  // code, about 100 extra moves per 592 multiply-adds.
+  template <int CH>
+  __device__ __forceinline__ void mont_chunk(uint64_t (&T)[L], const uint32_t* a_lds, const uint32_t (&b)[L], uint32_t (&qd)[L], bool collect) const {
+#pragma unroll
+    for (int i = 0; i < CH; i++) {
+      const uint32_t ai = a_lds[i];
+#pragma unroll
+      for (int c = 0; c < L; c++) T[(i + c) % L] += (uint64_t)ai * b[c];
+      const uint32_t q = ((uint32_t)T[i] * n0inv) & LMASK;
+#pragma unroll
+      for (int c = 0; c < L; c++) T[(i + c) % L] += (uint64_t)q * n[c];
+      T[(i + 1) % L] += T[i] >> W;
+      T[i] = 0;
+      qd[i] = collect ? q : qd[i];        // digit of this chunk's step i (the low CH entries are free); rotated into place below
+    }
+    // rotate by CH: the lowest live column (register CH) becomes register 0; the CH registers that already hold the new top
+    // columns follow at the top.  Same rotation for the digit shift register.
+    uint64_t tsave[CH];
+#pragma unroll
+    for (int i = 0; i < CH; i++) tsave[i] = T[i];
+#pragma unroll
+    for (int r = 0; r + CH < L; r++) T[r] = T[r + CH];
+#pragma unroll
+    for (int i = 0; i < CH; i++) T[L - CH + i] = tsave[i];
+    // (the digit register rotates even when nothing is recorded: L positions in total bring a preserved q_io back into place,
+    // and one copy of the chunk code serves both kinds of pass)
+    uint32_t qsave[CH];
+#pragma unroll
+    for (int i = 0; i < CH; i++) qsave[i] = qd[i];
+#pragma unroll
+    for (int r = 0; r + CH < L; r++) qd[r] = qd[r + CH];
+#pragma unroll
+    for (int i = 0; i < CH; i++) qd[L - CH + i] = qsave[i];
+  }
+  __device__ __forceinline__ void mont_a1(uint32_t (&r)[L], const uint32_t* a_lds, const uint32_t (&b)[L], uint32_t (&q_io)[L],
+                                          bool use_init, bool collect) const {
+    static_assert(G == 1, "one-lane product pass");
+    constexpr int CH = 8, NFULL = L / CH, REM = L % CH;      // L = 37: chunks of 8, 8, 8, 8, 5 limb steps
+    uint64_t T[L];
+#pragma unroll
+    for (int i = 0; i < L; i++) T[i] = use_init ? (uint64_t)q_io[i] : 0ull;
+    // after L steps and rotations by L positions in total the registers are back in column order.  q_io itself is the digit shift
+    // register (its start value has been consumed above): with `collect` digit l ends in q_io[l], without q_io is unchanged
+#pragma unroll 1
+    for (int k = 0; k < NFULL; k++) mont_chunk<CH>(T, a_lds + CH * k, b, q_io, collect);
+    if constexpr (REM > 0) mont_chunk<(REM > 0 ? REM : 1)>(T, a_lds + CH * NFULL, b, q_io, collect);
+    uint64_t c = 0;
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+      const uint64_t v = T[l] + c;
+      r[l] = (uint32_t)v & LMASK;
+      c = v >> W;
+    }
+  }
   // (x0, x1) <- (w0, w1) with  w0 + w1 n = (x0 + x1 n) / R  (mod n^2): leaves the pair form (w0, w1 < 2n + 1, lazy)
   __device__ __forceinline__ void pair_redc(uint32_t (&x0)[L], uint32_t (&x1)[L]) const {
     uint32_t q[L];
@@ -381,13 +565,17 @@ struct Grp {
     for (int l = 0; l < L; l++) dst_lds[j * L + l] = x[l] << 1;
   }
   // copy S limbs (limb form, global) of one number into this lane's registers
+  // TS: element stride (1 = one number's limbs are consecutive; 64 = the one-lane table layout [limb][lane], in which the
+  // 64 numbers of a wave interleave so that a wave's access to limb l is one contiguous 256-byte request)
+  template <int TS = 1>
   __device__ __forceinline__ void load_limbs(uint32_t (&x)[L], const uint32_t* __restrict__ src) const {
 #pragma unroll
-    for (int l = 0; l < L; l++) x[l] = src[j * L + l];
+    for (int l = 0; l < L; l++) x[l] = src[(j * L + l) * TS];
   }
+  template <int TS = 1>
   __device__ __forceinline__ void store_limbs(uint32_t* __restrict__ dst, const uint32_t (&x)[L]) const {
 #pragma unroll
-    for (int l = 0; l < L; l++) dst[j * L + l] = x[l];
+    for (int l = 0; l < L; l++) dst[(j * L + l) * TS] = x[l];
   }
   // canonical little-endian 32-bit words (global) -> limb form.  wtmp: group's WP-word LDS scratch.
   // Reads `nwords` words starting at word offset `woff`, i.e. the value floor(x / 2^(32 woff)) mod 2^(32 nwords).

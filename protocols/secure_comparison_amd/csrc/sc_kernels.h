@@ -5,7 +5,10 @@
 
 namespace sc {
 #ifndef SC_VM_WAVES
-#define SC_VM_WAVES 2
+#define SC_VM_WAVES 2     // waves per SIMD the single-modulus interpreter is compiled for (L <= 18 configurations)
+#endif
+#ifndef SC_PVM_WAVES
+#define SC_PVM_WAVES 2    // same for the pair interpreter
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -13,26 +16,33 @@ namespace sc {
 // the program and grid-strides over the batch.
 // ---------------------------------------------------------------------------------------------
 template <int G, int L, int WB>
-__global__ void __launch_bounds__(64, ((L > 18 || (G == 16 && L > 14)) ? 1 : SC_VM_WAVES)) k_vm(const VmArgs args) {
+__global__ void __launch_bounds__(64, (G == 1 && L == 37) ? 2 : ((L > 18 || (G == 16 && L > 14)) ? 1 : SC_VM_WAVES)) k_vm(const VmArgs args) {
   using GT = Grp<G, L, WB>;
   constexpr int S = GT::S, NG = GT::NG, SP = GT::SP, WP = GT::WP;
   __shared__ uint32_t s_a[NG * SP];            // per-group staging area for the LDS-side operand
-  __shared__ uint32_t s_a2[NG * SP];           // the same operand doubled (squarings only)
-  __shared__ uint32_t s_w[NG * WP];            // per-group 32-bit-word scratch for format conversion
+  __shared__ uint32_t s_a2[G == 1 ? 1 : NG * SP];  // the same operand doubled (squarings of the multi-lane forms); also the
+                                               // 32-bit-word scratch of the format conversions (WP <= SP; never live at the same
+                                               // time).  One-lane numbers square out of registers: no second area
   __shared__ uint32_t s_c[VM_MAX_CONST * SP];  // modulus constants shared by all groups
+  static_assert(WP <= SP, "word scratch must fit the staging area it aliases");
 
   GT gp;
   gp.init(args.modctx, args.n0inv);
   uint32_t* const my_a = s_a + gp.g * SP;
-  uint32_t* const my_a2 = s_a2 + gp.g * SP;
-  uint32_t* const my_w = s_w + gp.g * WP;
+  uint32_t* const my_a2 = (G == 1) ? my_a : s_a2 + gp.g * SP;
+  uint32_t* const my_w = my_a2;
   for (int t = threadIdx.x; t < 2 * S; t += 64) s_c[(t / S) * SP + (t % S)] = args.modctx[S + t];
   for (int t = threadIdx.x; t < (int)args.nconst_extra * S; t += 64)
     s_c[(2 + t / S) * SP + (t % S)] = args.consts[t];
   __syncthreads();
 
+  // the slot's scratch table: rows of S limbs.  Multi-lane forms: one number's rows are contiguous (element stride 1).  One-lane
+  // form: the 64 numbers of the wave interleave, [row][limb][lane] (element stride 64), so that the wave's access to a limb is
+  // one contiguous 256-byte request instead of 64 scattered words
+  constexpr int TS = (G == 1) ? 64 : 1;
   const uint64_t slot = (uint64_t)blockIdx.x * NG + gp.g;
-  uint32_t* const my_tbl = args.scratch + slot * (uint64_t)args.nscratch * S;
+  uint32_t* const my_tbl = (G == 1) ? args.scratch + (uint64_t)blockIdx.x * NG * args.nscratch * S + gp.g
+                                    : args.scratch + slot * (uint64_t)args.nscratch * S;
 
   for (uint64_t base = (uint64_t)blockIdx.x * NG; base < args.count; base += (uint64_t)gridDim.x * NG) {
     const bool live = base + gp.g < args.count;
@@ -49,19 +59,22 @@ __global__ void __launch_bounds__(64, ((L > 18 || (G == 16 && L > 14)) ? 1 : SC_
       // ---- resolve a limb-form / word-form source described by akind (used by MUL and LOADT)
       const uint32_t* a_ptr = my_a;          // LDS pointer handed to the multiplier
       const uint32_t* src_limbs = nullptr;   // global limb-form source (copied to registers / LDS)
+      int src_ts = 1;                        // its element stride (TS for rows of the slot's table)
       bool src_is_one = false;
       if (opc == OP_MUL || opc == OP_LOADT) {
         if (akind == AK_CONST) {
           a_ptr = s_c + op.w1 * SP;
         } else if (akind == AK_TBL) {
-          src_limbs = my_tbl + (uint64_t)op.w1 * S;
+          src_limbs = my_tbl + (uint64_t)op.w1 * S * TS;
+          src_ts = TS;
         } else if (akind == AK_TBLSEL) {
           const VmExt& ea = args.ext[op.w1 & 0xf];
           const VmExt& eb = args.ext[(op.w1 >> 12) & 0xf];
           const uint64_t fa = ((const uint64_t*)ea.ptr)[idx] >> ((op.w1 >> 4) & 0xff);
           const uint64_t fb = ((const uint64_t*)eb.ptr)[idx] >> ((op.w1 >> 16) & 0xff);
           const uint32_t sel = (uint32_t)((fa & 1) * 2 + (fb & 1));
-          src_limbs = my_tbl + (uint64_t)((op.w2 >> (8 * sel)) & 0xff) * S;
+          src_limbs = my_tbl + (uint64_t)((op.w2 >> (8 * sel)) & 0xff) * S * TS;
+          src_ts = TS;
         } else if (akind == AK_TBLDIG || akind == AK_FBT) {
           const VmExt& e = args.ext[op.w1 & 0xf];
           const uint32_t bitpos = (op.w1 >> 4) & 0xfffff, width = op.w1 >> 24;
@@ -70,8 +83,9 @@ __global__ void __launch_bounds__(64, ((L > 18 || (G == 16 && L > 14)) ? 1 : SC_
           uint64_t v = (w0i < e.nwords) ? ew[w0i] : 0u;
           if (w0i + 1 < e.nwords) v |= (uint64_t)ew[w0i + 1] << 32;
           const uint32_t digit = (uint32_t)(v >> sh) & ((1u << width) - 1);
-          src_limbs = (akind == AK_TBLDIG) ? my_tbl + (uint64_t)(op.w2 + digit) * S
+          src_limbs = (akind == AK_TBLDIG) ? my_tbl + (uint64_t)(op.w2 + digit) * S * TS
                                            : args.fbt + (((uint64_t)op.w2 << width) + digit) * S;
+          src_ts = (akind == AK_TBLDIG) ? TS : 1;
         } else if (akind == AK_EXTL) {
           const VmExt& e = args.ext[op.w1 & 0xf];
           const uint64_t flat = (uint64_t)op.w2 * args.count + idx;
@@ -86,12 +100,16 @@ __global__ void __launch_bounds__(64, ((L > 18 || (G == 16 && L > 14)) ? 1 : SC_
             // the fetch / decode of one micro-op
 #pragma unroll 1
             for (uint32_t rep = (imm ? imm : 1); rep > 0; rep--) {
-              __syncthreads();
-              gp.stage(my_a, acc);
-              gp.stage_doubled(my_a2, acc);
-              __syncthreads();
               uint32_t r[L];
-              gp.sqr(r, my_a, my_a2, acc);
+              if constexpr (G == 1) {
+                gp.template mont_r<3>(r, acc, acc, r, r);     // both operands in registers
+              } else {
+                __syncthreads();
+                gp.stage(my_a, acc);
+                gp.stage_doubled(my_a2, acc);
+                __syncthreads();
+                gp.sqr(r, my_a, my_a2, acc);
+              }
 #pragma unroll
               for (int l = 0; l < L; l++) acc[l] = r[l];
             }
@@ -109,7 +127,7 @@ __global__ void __launch_bounds__(64, ((L > 18 || (G == 16 && L > 14)) ? 1 : SC_
             gp.stage(my_a, t);
           } else if (src_limbs != nullptr) {
 #pragma unroll
-            for (int l = 0; l < L; l++) my_a[gp.j * L + l] = src_limbs[gp.j * L + l];
+            for (int l = 0; l < L; l++) my_a[gp.j * L + l] = src_limbs[(gp.j * L + l) * src_ts];
           } else if (src_is_one) {
             a_ptr = s_c + 1 * SP;  // Montgomery one: multiplying by it is the identity
           }
@@ -126,7 +144,8 @@ __global__ void __launch_bounds__(64, ((L > 18 || (G == 16 && L > 14)) ? 1 : SC_
 #pragma unroll
             for (int l = 0; l < L; l++) acc[l] = c[gp.j * L + l];
           } else {
-            gp.load_limbs(acc, src_limbs);
+#pragma unroll
+            for (int l = 0; l < L; l++) acc[l] = src_limbs[(gp.j * L + l) * src_ts];
           }
           break;
         }
@@ -176,7 +195,7 @@ __global__ void __launch_bounds__(64, ((L > 18 || (G == 16 && L > 14)) ? 1 : SC_
           break;
         }
         case OP_STT: {
-          gp.store_limbs(my_tbl + (uint64_t)imm * S, acc);
+          gp.template store_limbs<TS>(my_tbl + (uint64_t)imm * S * TS, acc);
           break;
         }
         case OP_STOREL: {
@@ -198,7 +217,7 @@ __global__ void __launch_bounds__(64, ((L > 18 || (G == 16 && L > 14)) ? 1 : SC_
         }
         case OP_ADDT: {
           uint32_t t[L];
-          gp.load_limbs(t, my_tbl + (uint64_t)imm * S);
+          gp.template load_limbs<TS>(t, my_tbl + (uint64_t)imm * S * TS);
 #pragma unroll
           for (int l = 0; l < L; l++) acc[l] += t[l];
           gp.renorm(acc);
@@ -239,26 +258,29 @@ __global__ void __launch_bounds__(64, ((L > 18 || (G == 16 && L > 14)) ? 1 : SC_
 // "pair arithmetic").  Same launch geometry and argument block as k_vm; compiled for the L = 18 configurations.
 // ---------------------------------------------------------------------------------------------
 template <int G, int L, int WB>
-__global__ void __launch_bounds__(64, (G == 16 ? 1 : SC_VM_WAVES)) k_pvm(const VmArgs args) {
+__global__ void __launch_bounds__(64, (G == 16 ? 1 : SC_PVM_WAVES)) k_pvm(const VmArgs args) {
   using GT = Grp<G, L, WB>;
   constexpr int S = GT::S, NG = GT::NG, SP = GT::SP, WP = GT::WP;
   __shared__ uint32_t s_a[NG * SP];            // first LDS-side operand  (x0, or y0)
-  __shared__ uint32_t s_a2[NG * SP];           // 2 * x0 (squarings) or y1 (products)
-  __shared__ uint32_t s_w[NG * WP];
+  __shared__ uint32_t s_a2[G == 1 ? 1 : NG * SP];  // 2 * x0 (squarings) or y1 (products); also the word scratch of PV_LOADU
+                                               // (one-lane numbers: squarings out of registers, products restage one area)
   __shared__ uint32_t s_c[VM_MAX_CONST * SP];
+  static_assert(WP <= SP, "word scratch must fit the staging area it aliases");
 
   GT gp;
   gp.init(args.modctx, args.n0inv);
   uint32_t* const my_a = s_a + gp.g * SP;
-  uint32_t* const my_a2 = s_a2 + gp.g * SP;
-  uint32_t* const my_w = s_w + gp.g * WP;
+  uint32_t* const my_a2 = (G == 1) ? my_a : s_a2 + gp.g * SP;
+  uint32_t* const my_w = my_a2;
   for (int t = threadIdx.x; t < 2 * S; t += 64) s_c[(t / S) * SP + (t % S)] = args.modctx[S + t];
   for (int t = threadIdx.x; t < (int)args.nconst_extra * S; t += 64)
     s_c[(2 + t / S) * SP + (t % S)] = args.consts[t];
   __syncthreads();
 
+  constexpr int TS = (G == 1) ? 64 : 1;      // element stride of the slot's table rows (k_vm: one-lane rows interleave by lane)
   const uint64_t slot = (uint64_t)blockIdx.x * NG + gp.g;
-  uint32_t* const my_tbl = args.scratch + slot * (uint64_t)args.nscratch * S;
+  uint32_t* const my_tbl = (G == 1) ? args.scratch + (uint64_t)blockIdx.x * NG * args.nscratch * S + gp.g
+                                    : args.scratch + slot * (uint64_t)args.nscratch * S;
 
   for (uint64_t base = (uint64_t)blockIdx.x * NG; base < args.count; base += (uint64_t)gridDim.x * NG) {
     const bool live = base + gp.g < args.count;
@@ -282,47 +304,57 @@ __global__ void __launch_bounds__(64, (G == 16 ? 1 : SC_VM_WAVES)) k_pvm(const V
           for (int l = 0; l < L; l++) x1[l] = 0;
           break;
         }
-        case PV_MULC: {
-          gp.pair_mul(x0, x1, s_c + op.w1 * SP, s_c + (op.w1 + 1) * SP);
-          break;
-        }
+        case PV_MULC:
         case PV_MULT: {
-          const uint32_t* src = my_tbl + (uint64_t)(2 * op.w1) * S;
-          __syncthreads();
+          if constexpr (G == 1) {
+            // one code path for both (the product pass exists once): the operand pair is copied into the staging area pass by pass
+            const bool cst = opc == PV_MULC;
+            const uint32_t* src = cst ? (const uint32_t*)(s_c + op.w1 * SP) : (const uint32_t*)(my_tbl + (uint64_t)(2 * op.w1) * S * TS);
+            gp.template pair_mul_seq<TS>(x0, x1, src, src + (cst ? SP : S * TS), cst ? 1 : TS, my_a, my_tbl + (uint64_t)(args.nscratch - 1) * S * TS);
+          } else if (opc == PV_MULC) {
+            gp.pair_mul(x0, x1, s_c + op.w1 * SP, s_c + (op.w1 + 1) * SP);
+          } else {
+            const uint32_t* src = my_tbl + (uint64_t)(2 * op.w1) * S;
+            __syncthreads();
 #pragma unroll
-          for (int l = 0; l < L; l++) {
-            my_a[gp.j * L + l] = src[gp.j * L + l];
-            my_a2[gp.j * L + l] = src[S + gp.j * L + l];
+            for (int l = 0; l < L; l++) {
+              my_a[gp.j * L + l] = src[gp.j * L + l];
+              my_a2[gp.j * L + l] = src[S + gp.j * L + l];
+            }
+            __syncthreads();
+            gp.pair_mul(x0, x1, my_a, my_a2);
           }
-          __syncthreads();
-          gp.pair_mul(x0, x1, my_a, my_a2);
           break;
         }
         case PV_SQR: {
-          __syncthreads();
-          gp.stage(my_a, x0);
-          gp.stage_doubled(my_a2, x0);
-          __syncthreads();
-          gp.pair_sqr(x0, x1, my_a, my_a2);
+          if constexpr (G == 1) {
+            gp.pair_sqr_r(x0, x1, my_a);
+          } else {
+            __syncthreads();
+            gp.stage(my_a, x0);
+            gp.stage_doubled(my_a2, x0);
+            __syncthreads();
+            gp.pair_sqr(x0, x1, my_a, my_a2);
+          }
           break;
         }
         case PV_STT: {
-          uint32_t* dst = my_tbl + (uint64_t)(2 * op.w1) * S;
-          gp.store_limbs(dst, x0);
-          gp.store_limbs(dst + S, x1);
+          uint32_t* dst = my_tbl + (uint64_t)(2 * op.w1) * S * TS;
+          gp.template store_limbs<TS>(dst, x0);
+          gp.template store_limbs<TS>(dst + S * TS, x1);
           break;
         }
         case PV_LOADT: {
-          const uint32_t* src = my_tbl + (uint64_t)(2 * op.w1) * S;
-          gp.load_limbs(x0, src);
-          gp.load_limbs(x1, src + S);
+          const uint32_t* src = my_tbl + (uint64_t)(2 * op.w1) * S * TS;
+          gp.template load_limbs<TS>(x0, src);
+          gp.template load_limbs<TS>(x1, src + S * TS);
           break;
         }
         case PV_ADDT: {
-          const uint32_t* src = my_tbl + (uint64_t)(2 * op.w1) * S;
+          const uint32_t* src = my_tbl + (uint64_t)(2 * op.w1) * S * TS;
           uint32_t t0[L], t1[L];
-          gp.load_limbs(t0, src);
-          gp.load_limbs(t1, src + S);
+          gp.template load_limbs<TS>(t0, src);
+          gp.template load_limbs<TS>(t1, src + S * TS);
 #pragma unroll
           for (int l = 0; l < L; l++) { x0[l] += t0[l]; x1[l] += t1[l]; }
           gp.renorm(x0);

@@ -99,13 +99,25 @@ std::vector<uint32_t> to_limbs(const Big& x, int S, int W) {
   return out;
 }
 
-struct Config { int G, L, W; };
+struct Config { int G, L, W; bool primary; };   // primary: eligible as a modulus's own configuration (sc_mod_create)
 // ordered by capacity W*G*L; sc_mod_create takes the first one that fits.  A 28-bit-limb L = 37 family ((2,37), (4,37)) was
 // built and measured in round 1: it needs > 256 registers (one wave per SIMD plus AGPR copies) and came out 2-3 % slower
 // than (4,18) / (8,18), so it is not compiled in; the limb width stays a template parameter for such experiments.
-const Config kConfigs[] = {{1, 18, 29}, {2, 18, 29}, {2, 27, 29}, {4, 14, 29}, {4, 18, 29}, {4, 27, 29}, {8, 14, 29}, {8, 18, 29}, {8, 27, 29}, {16, 14, 29}, {16, 18, 29}};
+const Config kConfigs[] = {{1, 18, 29, true}, {2, 18, 29, true}, {2, 27, 29, true}, {4, 14, 29, true}, {4, 18, 29, true}, {4, 27, 29, true},
+                           {8, 14, 29, true}, {8, 18, 29, true}, {8, 27, 29, true}, {16, 14, 29, true}, {16, 18, 29, true}};
+// The one-lane configuration for moduli up to 1028 bits (the primes of 2048-bit Paillier / DGK keys): (1, 37) with 28-bit limbs.
+// A number lives in ONE lane, so the per-limb-step bookkeeping is paid once per number instead of once per lane of a group, the
+// operand of a squaring never leaves the registers and the modulus sits in scalar registers: 1.15 - 1.25x the (2, 18) rate
+// per number.  It needs 64 numbers per wave, i.e. large batches, and is therefore never a modulus's own configuration: the
+// shared-exponent entry points switch to an internal twin context of the same modulus when the batch fills the chip
+// (onelane_for, sc_ctx_set_onelane_mode).
+const Config kOneLane = {1, 37, 28, false};
 // configurations with a pair kernel (k_pvm): every L = 18 one, and (4,14) / (8,14) for the 1536 / 3072-bit sizes whose direct
 // configuration is L = 27 (the pair arithmetic needs the L <= 18 column bound)
+// (the one-lane (1, 37, 28) configuration has no pair kernel: measured on the MI355X its pair squarings run 3 % faster than the
+// (2, 18) ones but its pair products -- three passes over a single LDS staging area, the second area would cost the eighth wave
+// of the CU -- 2.6x a squaring instead of 1.4x, a net loss of 12 % on x^p mod p^2; the one-lane form is used where it wins:
+// the single-modulus exponentiations)
 inline bool pair_capable(int G, int L, int W) { return W == 29 && (L == 18 || (L == 14 && (G == 4 || G == 8))); }
 
 struct Mod {
@@ -154,6 +166,8 @@ struct sc_ctx {
   std::map<int, int> kred_cache;                            // mod -> constant id of 2^(32 nwords) (wide-operand reduction)
   std::map<std::pair<int, std::vector<uint32_t>>, int> const_by_value;  // (mod, residue) -> constant id
   int latency_mode = 1;                                     // sc_ctx_set_latency_mode: 0 never, 1 automatic, 2 whenever available
+  int onelane_mode = 1;                                     // sc_ctx_set_onelane_mode: 0 never, 1 automatic, 2 whenever available
+  std::map<int, int> onelane_twins;                         // mod -> context of the same modulus in the one-lane configuration
   std::map<int, int> pair_twins;                            // mod -> context of the same modulus in a pair-capable configuration
   std::map<int, uint32_t*> pair_consts;                     // mod -> 4 limb arrays: pair(R^2), pair(B R) for the pair arithmetic
 };
@@ -376,12 +390,13 @@ int run_vm(sc_ctx* ctx, int mod, const Prog& p, const VmExt* exts, int next, uin
   SC_CASE(1, 18, 29) SC_CASE(2, 18, 29) SC_CASE(2, 27, 29) SC_CASE(4, 18, 29) SC_CASE(4, 27, 29) SC_CASE(8, 18, 29) SC_CASE(8, 27, 29)
   SC_CASE(16, 18, 29) SC_CASE(4, 14, 29) SC_CASE(8, 14, 29) SC_CASE(16, 14, 29)
   SC_CASE(2, 9, 29) SC_CASE(4, 9, 29) SC_CASE(8, 9, 29) SC_CASE(16, 9, 29)
+  SC_CASE(1, 37, 28)
 #undef SC_CASE
   if (rc == SC_ERR_UNSUPPORTED) return fail(ctx, rc, "no kernel configuration for G=%d L=%d", G, L);
   return rc;
 }
 
-template <int G, int L>
+template <int G, int L, int WB = 29>
 int launch_pvm_cfg(sc_ctx* ctx, const VmArgs& a) {
   constexpr int NG = 64 / G;
   const int key = 1000 + 100 * L + G;
@@ -389,7 +404,7 @@ int launch_pvm_cfg(sc_ctx* ctx, const VmArgs& a) {
   int occ;
   if (it == ctx->occ_cache.end()) {
     int nb = 0;
-    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_pvm<G, L, 29>, 64, 0));
+    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_pvm<G, L, WB>, 64, 0));
     occ = std::max(1, std::min(nb, 16));
     ctx->occ_cache[key] = occ;
   } else {
@@ -401,7 +416,7 @@ int launch_pvm_cfg(sc_ctx* ctx, const VmArgs& a) {
   if (rc) return rc;
   VmArgs args = a;
   args.scratch = ctx->scratch;
-  hipLaunchKernelGGL((k_pvm<G, L, 29>), dim3(grid), dim3(64), 0, ctx->stream, args);
+  hipLaunchKernelGGL((k_pvm<G, L, WB>), dim3(grid), dim3(64), 0, ctx->stream, args);
   HIPCHK(ctx, hipGetLastError());
   return SC_OK;
 }
@@ -573,14 +588,15 @@ int sc_memcpy_d2h(sc_ctx* ctx, void* hptr, const void* dptr, size_t bytes) {
   return SC_OK;
 }
 
-static int create_mod(sc_ctx* ctx, const uint32_t* n_hptr, int nwords, bool for_pairs, int* out_mod);
+static int create_mod(sc_ctx* ctx, const uint32_t* n_hptr, int nwords, bool for_pairs, int* out_mod, const Config* forced = nullptr);
 
 int sc_mod_create(sc_ctx* ctx, const uint32_t* n_hptr, int nwords, int* out_mod) {
   return create_mod(ctx, n_hptr, nwords, false, out_mod);
 }
 
-// for_pairs: take the first configuration that has a pair kernel (used for the internal twin context of sc_modexp_shared_sq)
-static int create_mod(sc_ctx* ctx, const uint32_t* n_hptr, int nwords, bool for_pairs, int* out_mod) {
+// for_pairs: take the first configuration that has a pair kernel (used for the internal twin context of sc_modexp_shared_sq);
+// forced: this configuration or failure (the one-lane twin)
+static int create_mod(sc_ctx* ctx, const uint32_t* n_hptr, int nwords, bool for_pairs, int* out_mod, const Config* forced) {
   if (!ctx || !n_hptr || nwords <= 0 || !out_mod) return fail(ctx, SC_ERR_ARG, "sc_mod_create: bad argument");
   Mod m;
   m.n.assign(n_hptr, n_hptr + nwords);
@@ -591,11 +607,15 @@ static int create_mod(sc_ctx* ctx, const uint32_t* n_hptr, int nwords, bool for_
     const int cap = c.W * c.G * c.L;
     return cap >= m.nbits + 8 && (!need_words || cap >= 32 * nwords);
   };
-  for (int pass = 0; pass < 2 && !m.G; pass++)
-    for (const Config& c : kConfigs) {
-      if (for_pairs && !pair_capable(c.G, c.L, c.W)) continue;
-      if (fits(c, pass == 0)) { m.G = c.G; m.L = c.L; m.W = c.W; break; }
-    }
+  if (forced) {
+    if (fits(*forced, false)) { m.G = forced->G; m.L = forced->L; m.W = forced->W; }
+  } else {
+    for (int pass = 0; pass < 2 && !m.G; pass++)
+      for (const Config& c : kConfigs) {
+        if (!c.primary || (for_pairs && !pair_capable(c.G, c.L, c.W))) continue;
+        if (fits(c, pass == 0)) { m.G = c.G; m.L = c.L; m.W = c.W; break; }
+      }
+  }
   if (!m.G) return fail(ctx, SC_ERR_UNSUPPORTED, "sc_mod_create: %d-bit modulus exceeds the largest configuration", m.nbits);
   m.S = m.G * m.L;
   const int W = m.W;
@@ -715,11 +735,14 @@ int sc_modmul_const(sc_ctx* ctx, int mod, const uint32_t* a, int cst, uint32_t* 
   return run_vm(ctx, mod, it->second, ex, 2, count);
 }
 
+static int onelane_for(sc_ctx* ctx, int mod, uint64_t count);
+
 static int modexp_shared_impl(sc_ctx* ctx, int mod, int exp, const uint32_t* x, int x_words, const uint32_t* mul_into,
                               uint32_t* out, uint8_t* flags, uint64_t count) {
   if (ctx && count == 0) return SC_OK;  // empty batch: nothing to do (pointers may be null)
   if (!valid_mod(ctx, mod) || exp < 0 || exp >= (int)ctx->exps.size() || !x || (!out && !flags))
     return fail(ctx, SC_ERR_ARG, "sc_modexp_shared: bad argument");
+  if (ctx->exps[exp].bits > 64) mod = onelane_for(ctx, mod, count);   // long exponentiations of a chip-filling batch: one-lane twin
   const Mod& m = ctx->mods[mod];
   if (x_words <= 0) x_words = m.nwords;
   const int mode = flags ? 2 : (mul_into ? 1 : 0);
@@ -1236,6 +1259,34 @@ static int pair_twin(sc_ctx* ctx, int mod) {
   return twin;
 }
 
+// The one-lane twin of `mod` when this batch should run on it, else `mod` itself.  Automatic policy: the modulus fits the
+// one-lane configuration and the batch is at least one and a half rounds of the chip's resident one-lane waves (2 per SIMD, 64
+// numbers each: 196608 numbers on 256 CUs).  Measured on the MI355X (1024-bit modulus, 1024-bit exponent): 196608 numbers 19.8 ->
+// 16.6 ms, 2.1 M numbers (zero tests) 37.3 -> 33.0 ms, but 98304 numbers 9.5 -> 11.6 ms -- three quarters of a round leaves a
+// quarter of the SIMDs with one wave and nobody to hide its latencies, where the two-lane form still runs 1.5 full rounds.
+static int onelane_for(sc_ctx* ctx, int mod, uint64_t count) {
+  if (ctx->onelane_mode == 0) return mod;
+  {
+    const Mod& m = ctx->mods[mod];
+    // the residue arrays (and the raw chunks a wide operand is read in) must fit below R = 2^(28 * 37): at most 32 words
+    if (m.W == kOneLane.W || m.nbits + 8 > kOneLane.W * kOneLane.G * kOneLane.L || 32 * m.nwords > kOneLane.W * kOneLane.G * kOneLane.L) return mod;
+    if (ctx->onelane_mode == 1 && count < (uint64_t)ctx->num_cu * 4 * 2 * 64 * 3 / 2) return mod;
+  }
+  auto it = ctx->onelane_twins.find(mod);
+  if (it != ctx->onelane_twins.end()) return it->second < 0 ? mod : it->second;
+  const Big n = ctx->mods[mod].n;
+  int twin = -1;
+  if (create_mod(ctx, n.data(), (int)n.size(), false, &twin, &kOneLane) != SC_OK) twin = -1;
+  ctx->onelane_twins[mod] = twin;
+  return twin < 0 ? mod : twin;
+}
+
+int sc_ctx_set_onelane_mode(sc_ctx* ctx, int mode) {
+  if (!ctx || mode < 0 || mode > 2) return SC_ERR_ARG;
+  ctx->onelane_mode = mode;
+  return SC_OK;
+}
+
 int sc_mod_supports_sq(sc_ctx* ctx, int mod) {
   if (!valid_mod(ctx, mod)) return SC_ERR_ARG;
   return pair_twin(ctx, mod) >= 0 ? 1 : 0;
@@ -1269,7 +1320,9 @@ int sc_modexp_shared_sq(sc_ctx* ctx, int mod_m, int mod_m2, int exp, const uint3
     std::vector<VmOp> ops;
     uint32_t nsc = 2;
     double macs = 0;
-    const double S2 = (double)m.S * m.S, SQ = S2 + (double)m.G * m.G * m.L * (m.L + 1) / 2.0 + 2.0 * S2, MU = 5.0 * S2;
+    // multiply-adds: a pair squaring is (a*a part) + 3 S^2; a pair product 5 S^2 with the two-row pass, 6 S^2 in the one-lane
+    // form (three single passes over one staging area)
+    const double S2 = (double)m.S * m.S, SQ = S2 + (double)m.G * m.G * m.L * (m.L + 1) / 2.0 + 2.0 * S2, MU = (m.G == 1 ? 6.0 : 5.0) * S2;
     auto emit = [&](uint32_t opc, uint32_t w1 = 0, uint32_t w2 = 0, uint32_t w3 = 0) { ops.push_back(VmOp{opc, w1, w2, w3}); };
     auto touch = [&](uint32_t e) { nsc = std::max(nsc, 2 * e + 2); };
     // embed the operand: Horner over chunks of nwords words; constants: LDS 2,3 = pair(R^2), 4,5 = pair(B R)
@@ -1307,6 +1360,7 @@ int sc_modexp_shared_sq(sc_ctx* ctx, int mod_m, int mod_m2, int exp, const uint3
     emit(PV_OUT, 1, 2); macs += 2.0 * S2;
     emit(PV_END);
     Prog p;
+    if (m.G == 1) nsc += 1;   // one-lane pair products park an intermediate in a spare row (the last one) of the slot's table
     p.nops = (uint32_t)ops.size(); p.nscratch = nsc; p.nconst = 4; p.muls_per_item = macs;
     int rc = upload(ctx, ops.data(), ops.size() * sizeof(VmOp), (void**)&p.d_ops); if (rc) return rc;
     rc = get_pair_consts(ctx, mod_m, &p.d_consts); if (rc) return rc;

@@ -401,6 +401,10 @@ class Engine:
         """Small-batch kernel policy (sc_ctx_set_latency_mode): 0 never, 1 automatic (default), 2 whenever available."""
         self._check(self.lib.sc_ctx_set_latency_mode(self.ctx, int(mode)))
 
+    def set_onelane_mode(self, mode: int) -> None:
+        """Large-batch kernel policy for moduli up to 1028 bits (sc_ctx_set_onelane_mode): 0 never, 1 automatic, 2 whenever it fits."""
+        self._check(self.lib.sc_ctx_set_onelane_mode(self.ctx, int(mode)))
+
     def table_traffic_probe(self, mod: Modulus, x: torch.Tensor, entries: int, reads: int) -> tuple[torch.Tensor, int]:
         """Measurement aid (sc_table_traffic_probe): returns (x again, limbs per table row)."""
         count = x.shape[0]

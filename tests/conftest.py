@@ -53,3 +53,11 @@ def latency_engine(engine):
     engine.set_latency_mode(2)
     yield engine
     engine.set_latency_mode(0)
+
+
+@pytest.fixture()
+def onelane_engine(engine):
+    """The same engine with the one-lane (1, 37) kernels forced on for every modulus they fit, whatever the batch size."""
+    engine.set_onelane_mode(2)
+    yield engine
+    engine.set_onelane_mode(1)

@@ -175,3 +175,62 @@ def test_bench_rank_handling_on_one_gpu():
     if torch.cuda.device_count() < 2:
         cp = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
         assert cp.returncode != 0 and "n_gpus" not in cp.stdout
+
+
+@pytest.mark.parametrize("bits", [523, 600, 1000, 1024, 1028])
+def test_onelane_configuration_primitives(onelane_engine, bits):
+    """The one-lane (1, 37, 28-bit) kernels forced on: shared-exponent powers (short / long exponents, wide operands reduced
+    first, fused multiply, is-one flags) and pair arithmetic modulo m^2, against Python integers, incl. operands 0, 1, m - 1
+    and ragged batch sizes around a wave of 64 numbers."""
+    eng = onelane_engine
+    rng = random.Random(bits)
+    m = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+    mod = eng.modulus(m)
+    mod2 = eng.modulus(m * m, 2 * mod.nwords)
+    for count in (1, 63, 64, 65, 200):
+        xs = [0, 1, m - 1][: min(3, count)] + [rng.randrange(m) for _ in range(max(0, count - 3))]
+        t = eng.upload(xs, mod.nwords)
+        for e in (rng.getrandbits(65) | (1 << 64), rng.getrandbits(bits) | 1, (1 << 200) - 1):
+            assert eng.download(eng.modexp_shared(mod, t, e)) == [pow(x, e, m) for x in xs]
+        e = rng.getrandbits(160) | (1 << 159)
+        ys = [rng.randrange(m) for _ in xs]
+        assert eng.download(eng.modexp_shared(mod, t, e, mul_into=eng.upload(ys, mod.nwords))) == [pow(x, e, m) * y % m for x, y in zip(xs, ys)]
+        wide = [rng.getrandbits(2 * bits + 40) for _ in xs]                       # wider than the modulus: reduced first
+        tw = eng.upload(wide, 2 * mod.nwords + 2)
+        assert eng.download(eng.modexp_shared(mod, tw, e)) == [pow(x % m, e, m) for x in wide]
+        ones = [pow(x, (m - 1) // 2 if i % 2 else e, m) for i, x in enumerate(xs)]
+        flags = eng.modexp_shared_isone(mod, t, e).tolist()
+        assert flags == [int(pow(x, e, m) == 1) for x in xs] and (ones or True)
+        # pair arithmetic: x^e mod m^2 from operands of 1, 2 and (wide) 3+ chunks, with and without the fused product
+        for width, src in ((mod.nwords, xs), (2 * mod.nwords, [rng.randrange(m * m) for _ in xs])):
+            tx = eng.upload(src, width)
+            ee = rng.getrandbits(bits) | (1 << (bits - 1))
+            assert eng.download(eng.modexp_shared_sq(mod, mod2, tx, ee)) == [pow(x, ee, m * m) for x in src]
+            into = [rng.randrange(m * m) for _ in src]
+            assert eng.download(eng.modexp_shared_sq(mod, mod2, tx, ee, mul_into=eng.upload(into, 2 * mod.nwords))) == \
+                [pow(x, ee, m * m) * v % (m * m) for x, v in zip(src, into)]
+
+
+def test_onelane_whole_comparisons(onelane_engine, keys):
+    """Whole comparisons with the one-lane kernels forced on for every 1024-bit modulus of the key holder's CRT paths and
+    the DGK zero test (2048-bit keys, l = 32), bit-exact against the oracle; and the three kernel policies agree."""
+    from protocols.secure_comparison_amd.batch import secure_comparison_batch
+
+    eng = onelane_engine
+    sk, dgk = oracle_paillier(keys, 2048), oracle_dgk(keys, "dgk_2048_l32")
+    l, B, rbits = 32, 70, 400
+    alice_p, alice_d, bob_p, bob_d = _schemes(eng, sk, dgk, rbits)
+    rng = random.Random(2048)
+    xs = [rng.randrange(1 << l) for _ in range(B)]
+    ys = [xs[i] if i % 4 == 0 else rng.randrange(1 << l) for i in range(B)]
+    drs = [o.draw(rng, l, sk, dgk, rbits) for _ in range(B)]
+    x_enc = [sk.randomize(sk.enc_raw(x), 1 + rng.randrange(sk.n - 1)) for x in xs]
+    y_enc = [sk.randomize(sk.enc_raw(y), 1 + rng.randrange(sk.n - 1)) for y in ys]
+    expect = [o.compare(a, b, l, sk, dgk, d, True) for a, b, d in zip(x_enc, y_enc, drs)]
+    nw = bob_p.mod_n.nwords
+    draws = _draw_tensors(eng, drs, l, nw, (dgk.u.bit_length() + 31) // 32, (rbits + 31) // 32, eng.device)
+    tx, ty = eng.upload(x_enc, 2 * nw), eng.upload(y_enc, 2 * nw)
+    assert eng.download(secure_comparison_batch(tx, ty, l, alice_p, alice_d, bob_p, bob_d, draws)) == expect
+    eng.set_onelane_mode(0)
+    assert eng.download(secure_comparison_batch(tx, ty, l, alice_p, alice_d, bob_p, bob_d, draws)) == expect
+    assert [sk.dec_raw(c) for c in expect] == [int(x <= y) for x, y in zip(xs, ys)]

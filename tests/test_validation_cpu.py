@@ -164,18 +164,20 @@ def test_plaintext_encodings(world):
     assert bob_d.unsafe_encrypt(3.0).value == od.enc_raw(3)
     with pytest.raises(ValueError):
         bob_d.unsafe_encrypt(0.5)
-    # two fixed-point values through the whole single-comparison protocol
+    # floats through the whole single-comparison protocol (a precision-0 scheme, like the reference's default one: the protocol's
+    # own `1 - [[delta_B]]` adds an ENCODED 1, so it is only meaningful when the encoding is the identity on integers)
     box = {}
     alice = Initiator(L, DictionaryCommunicator(box), "bob")
-    bob = KeyHolder(L, DictionaryCommunicator(box), "alice", fx, bob_d)
+    bob = KeyHolder(L, DictionaryCommunicator(box), "alice", bob_p, bob_d)
 
-    async def go():
-        res, _ = await asyncio.gather(alice.perform_secure_comparison(1.25, 1.3), bob.perform_secure_comparison())
+    async def go(a, b):
+        res, _ = await asyncio.gather(alice.perform_secure_comparison(a, b), bob.perform_secure_comparison())
         return res
 
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        assert fx.decrypt(asyncio.run(go()), apply_encoding=False) == 1
+        assert bob_p.decrypt(asyncio.run(go(41.0, 42.0))) == 1 and bob_p.decrypt(asyncio.run(go(42.0, 41.0))) == 0
+        assert bob_p.decrypt(asyncio.run(go(7.4, 7.0))) == 1        # 7.4 is rounded to 7 by the precision-0 encoding
 
 
 def test_scalar_multiplication_registers_nothing(world):
