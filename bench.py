@@ -101,12 +101,13 @@ def synth_inputs(eng, l, alice_p, bob_p, bob_d, B, rbits, seed, shuffle=False):
     else:  # l = 64: u has 67 bits; draw 66 random bits (always < u) and force non-zero
         rhos = rand_words(l + 1, B, ew, top_bits_clear=32 * ew - (u.bit_length() - 1))
         rhos[..., 0] |= 1
+    rho_bob = below_n(3 * B)    # the key holder's three randomizer inputs as row blocks of one array (joined again without a copy)
     draws = BatchDraws(
         r=below_n(B), delta_a=torch.randint(0, 2, (B,), generator=g, device=dev, dtype=torch.int64), rhos=rhos,
         permutation=None, rho_z=below_n(B),
         r_bob_dgk=rand_words(l + 1, B, er, top_bits_clear=32 * er - rbits),
         r_alice_dgk=rand_words(l + 1, B, er, top_bits_clear=32 * er - rbits),
-        rho_zeta_1=below_n(B), rho_zeta_2=below_n(B), rho_delta_b=below_n(B))
+        rho_zeta_1=rho_bob[:B], rho_zeta_2=rho_bob[B:2 * B], rho_delta_b=rho_bob[2 * B:])
     if shuffle:   # drawn last so that the other inputs of a seed do not depend on the flag
         draws.permutation = torch.argsort(torch.rand((B, l + 1), generator=g, device=dev, dtype=torch.float64), dim=1)
     return x, y, x_enc, y_enc, draws

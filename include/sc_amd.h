@@ -119,6 +119,13 @@ int sc_fixedbase_pow(sc_ctx* ctx, int fbt, const uint32_t* e_dptr, int ewords,
 int sc_modexp_var(sc_ctx* ctx, int mod, const uint32_t* x_dptr, const uint32_t* e_dptr, int ewords, int ebits,
                   int fbt /* -1 = none */, const uint32_t* e2_dptr, int e2words, uint32_t* out_dptr,
                   uint64_t count);
+/* The same with the result of item i stored at row dest_index[i] of out[count][nwords] (uint64 per item): the per-comparison
+ * shuffle of the blinded c-vector (SC/initiator.py:212-226, :516) happens in the store of the blinding launch instead of a
+ * separate gather pass over the 0.5 GB vector.  dest_index should be a permutation of 0 .. count-1; rows >= count are dropped
+ * (never written out of bounds), rows named twice keep one of the values. */
+int sc_modexp_var_scatter(sc_ctx* ctx, int mod, const uint32_t* x_dptr, const uint32_t* e_dptr, int ewords, int ebits,
+                          int fbt /* -1 = none */, const uint32_t* e2_dptr, int e2words, const uint64_t* dest_index_dptr,
+                          uint32_t* out_dptr, uint64_t count);
 /* out[i] = x[i]^-1 mod n (Montgomery's simultaneous inversion + an on-device binary extended GCD):
  * ct * -1 / int - ct / ct - ct (SC/initiator.py:254, 320, 371, 466, 478, 531, 559).
  * Synchronous.  On SC_ERR_NOT_INVERTIBLE *bad_index (nullable) is the index of a non-invertible element (found by testing

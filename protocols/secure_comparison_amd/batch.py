@@ -10,6 +10,7 @@ from dataclasses import dataclass
 
 import torch
 
+from ._views import cat_rows
 from .initiator import Initiator
 from .keyholder import KeyHolder
 from .schemes import DGK, Paillier
@@ -80,8 +81,8 @@ def secure_comparison_batch(x_enc: torch.Tensor, y_enc: torch.Tensor, l: int, al
     zeta_1_enc, zeta_2_enc, delta_b_enc = KeyHolder.step_5_batch(b_plain, delta_b, bob_paillier)
     if randomize:
         count = zeta_1_enc.shape[0]
-        rnd = bob_paillier.randomize_batch(torch.cat([zeta_1_enc, zeta_2_enc, delta_b_enc], dim=0),
-                                           torch.cat([draws.rho_zeta_1, draws.rho_zeta_2, draws.rho_delta_b], dim=0))
+        rnd = bob_paillier.randomize_batch(cat_rows([zeta_1_enc, zeta_2_enc, delta_b_enc]),     # three blocks of one array: a view
+                                           cat_rows([draws.rho_zeta_1, draws.rho_zeta_2, draws.rho_delta_b]))
         zeta_1_enc, zeta_2_enc, delta_b_enc = rnd[:count], rnd[count:2 * count], rnd[2 * count:]
     # Alice: steps 6, 7
     result = Initiator.step_6_7_batch(draws.delta_a, delta_b_enc, zeta_1_enc, zeta_2_enc, a_plain, l, alice_paillier)
@@ -99,14 +100,14 @@ def _secure_comparison_batch_pooled(x_enc, y_enc, l, alice_paillier, alice_dgk, 
     b_plain = KeyHolder.step_2_batch(z_enc, l, bob_paillier)
     d_enc, beta_enc = KeyHolder.step_4a_4b_batch(b_plain, l, bob_dgk, bob_paillier, None)
     nw = d_enc.shape[-1]
-    rnd = bob_dgk.randomize_from_pool_batch(torch.cat([d_enc.reshape(1, count, nw), beta_enc], dim=0).reshape((l + 1) * count, nw))
+    rnd = bob_dgk.randomize_from_pool_batch(cat_rows([d_enc.reshape(1, count, nw), beta_enc]).reshape((l + 1) * count, nw))
     rnd = rnd.reshape(l + 1, count, nw)
     d_enc, beta_enc = rnd[0].contiguous(), rnd[1:].contiguous()
     c_h = Initiator.step_4c_to_4h_batch(d_enc, beta_enc, a_plain, draws.delta_a, alice_dgk)
     c = Initiator.step_4i_batch(c_h, alice_dgk, draws.rhos, draws.permutation, None)
     c_sent = alice_dgk.randomize_from_pool_batch(c.reshape((l + 1) * count, nw)).reshape(l + 1, count, nw)
     delta_b = KeyHolder.step_4j_batch(c_sent, bob_dgk)
-    triple = bob_paillier.randomize_from_pool_batch(torch.cat(KeyHolder.step_5_batch(b_plain, delta_b, bob_paillier), dim=0))
+    triple = bob_paillier.randomize_from_pool_batch(cat_rows(KeyHolder.step_5_batch(b_plain, delta_b, bob_paillier)))
     return Initiator.step_6_7_batch(draws.delta_a, triple[2 * count:], triple[:count], triple[count:2 * count], a_plain, l, alice_paillier)
 
 

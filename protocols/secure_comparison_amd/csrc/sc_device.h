@@ -16,6 +16,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Every kernel of the library runs 64-thread workgroups, i.e. ONE wave: the lanes of a wave execute LDS instructions in
+// program order, so a compiler-level wave barrier would be enough to order the staging writes before the reads.  Measured on the
+// MI355X (-DSC_WAVE_BARRIER_ONLY, tools/gpu_kernel_rates.py): no difference to __syncthreads() in any launch group -- an s_barrier
+// of a one-wave workgroup costs nothing -- so the hardware barrier stays.
+#ifdef SC_WAVE_BARRIER_ONLY
+#define SC_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#else
+#define SC_WAVE_SYNC() __syncthreads()
+#endif
+
 namespace sc {
 
 constexpr int W_DEFAULT = 29;  // limb width of the standard configurations (a 28-bit family exists for L = 37)
@@ -581,9 +591,9 @@ struct Grp {
   // Reads `nwords` words starting at word offset `woff`, i.e. the value floor(x / 2^(32 woff)) mod 2^(32 nwords).
   __device__ __forceinline__ void load_words(uint32_t (&x)[L], const uint32_t* __restrict__ src, int nwords,
                                              uint32_t* wtmp) const {
-    __syncthreads();
+    SC_WAVE_SYNC();
     for (int t = j; t < WP; t += G) wtmp[t] = (t < nwords) ? src[t] : 0u;
-    __syncthreads();
+    SC_WAVE_SYNC();
 #pragma unroll
     for (int l = 0; l < L; l++) {
       const int bit = W * (j * L + l);
@@ -595,10 +605,10 @@ struct Grp {
   // exact limbs -> canonical 32-bit words (global).  ltmp: group's SP-limb LDS scratch.
   __device__ __forceinline__ void store_words(uint32_t* __restrict__ dst, int nwords, const uint32_t (&x)[L],
                                               uint32_t* ltmp, bool pred) const {
-    __syncthreads();
+    SC_WAVE_SYNC();
     stage(ltmp, x);
     if (j == 0) { ltmp[S] = 0; ltmp[S + 1] = 0; ltmp[S + 2] = 0; }
-    __syncthreads();
+    SC_WAVE_SYNC();
     if (pred) {
       for (int t = j; t < nwords; t += G) {
         const int bit = 32 * t;

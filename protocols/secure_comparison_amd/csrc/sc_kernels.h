@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(64, (G == 1 && L == 37) ? 2 : ((L > 18 || (G =
   for (int t = threadIdx.x; t < 2 * S; t += 64) s_c[(t / S) * SP + (t % S)] = args.modctx[S + t];
   for (int t = threadIdx.x; t < (int)args.nconst_extra * S; t += 64)
     s_c[(2 + t / S) * SP + (t % S)] = args.consts[t];
-  __syncthreads();
+  SC_WAVE_SYNC();
 
   // the slot's scratch table: rows of S limbs.  Multi-lane forms: one number's rows are contiguous (element stride 1).  One-lane
   // form: the 64 numbers of the wave interleave, [row][limb][lane] (element stride 64), so that the wave's access to a limb is
@@ -104,10 +104,10 @@ __global__ void __launch_bounds__(64, (G == 1 && L == 37) ? 2 : ((L > 18 || (G =
               if constexpr (G == 1) {
                 gp.template mont_r<3>(r, acc, acc, r, r);     // both operands in registers
               } else {
-                __syncthreads();
+                SC_WAVE_SYNC();
                 gp.stage(my_a, acc);
                 gp.stage_doubled(my_a2, acc);
-                __syncthreads();
+                SC_WAVE_SYNC();
                 gp.sqr(r, my_a, my_a2, acc);
               }
 #pragma unroll
@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(64, (G == 1 && L == 37) ? 2 : ((L > 18 || (G =
             }
             break;
           }
-          __syncthreads();
+          SC_WAVE_SYNC();
           if (akind == AK_EXTW) {
             const VmExt& e = args.ext[op.w1 & 0xf];
             const uint64_t flat = (uint64_t)op.w2 * args.count + idx;
@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(64, (G == 1 && L == 37) ? 2 : ((L > 18 || (G =
           } else if (src_is_one) {
             a_ptr = s_c + 1 * SP;  // Montgomery one: multiplying by it is the identity
           }
-          __syncthreads();
+          SC_WAVE_SYNC();
           uint32_t r[L];
           gp.mul(r, a_ptr, acc);
 #pragma unroll
@@ -179,7 +179,8 @@ __global__ void __launch_bounds__(64, (G == 1 && L == 37) ? 2 : ((L > 18 || (G =
         case OP_STOREW: {
           gp.canonical(acc);
           const VmExt& e = args.ext[op.w1 & 0xf];
-          const uint64_t flat = (uint64_t)op.w2 * args.count + idx;
+          uint64_t flat = (uint64_t)op.w2 * args.count + idx;
+          if (op.w3) flat = ((const uint64_t*)args.ext[(op.w3 - 1) & 0xf].ptr)[idx];   // scatter (the shuffle of step 4i); guarded by e.limit
           gp.store_words((uint32_t*)e.ptr + flat * e.stride, e.nwords, acc, my_a, live && flat < e.limit);
           break;
         }
@@ -275,7 +276,7 @@ __global__ void __launch_bounds__(64, (G == 16 ? 1 : SC_PVM_WAVES)) k_pvm(const 
   for (int t = threadIdx.x; t < 2 * S; t += 64) s_c[(t / S) * SP + (t % S)] = args.modctx[S + t];
   for (int t = threadIdx.x; t < (int)args.nconst_extra * S; t += 64)
     s_c[(2 + t / S) * SP + (t % S)] = args.consts[t];
-  __syncthreads();
+  SC_WAVE_SYNC();
 
   constexpr int TS = (G == 1) ? 64 : 1;      // element stride of the slot's table rows (k_vm: one-lane rows interleave by lane)
   const uint64_t slot = (uint64_t)blockIdx.x * NG + gp.g;
@@ -315,13 +316,13 @@ __global__ void __launch_bounds__(64, (G == 16 ? 1 : SC_PVM_WAVES)) k_pvm(const 
             gp.pair_mul(x0, x1, s_c + op.w1 * SP, s_c + (op.w1 + 1) * SP);
           } else {
             const uint32_t* src = my_tbl + (uint64_t)(2 * op.w1) * S;
-            __syncthreads();
+            SC_WAVE_SYNC();
 #pragma unroll
             for (int l = 0; l < L; l++) {
               my_a[gp.j * L + l] = src[gp.j * L + l];
               my_a2[gp.j * L + l] = src[S + gp.j * L + l];
             }
-            __syncthreads();
+            SC_WAVE_SYNC();
             gp.pair_mul(x0, x1, my_a, my_a2);
           }
           break;
@@ -330,10 +331,10 @@ __global__ void __launch_bounds__(64, (G == 16 ? 1 : SC_PVM_WAVES)) k_pvm(const 
           if constexpr (G == 1) {
             gp.pair_sqr_r(x0, x1, my_a);
           } else {
-            __syncthreads();
+            SC_WAVE_SYNC();
             gp.stage(my_a, x0);
             gp.stage_doubled(my_a2, x0);
-            __syncthreads();
+            SC_WAVE_SYNC();
             gp.pair_sqr(x0, x1, my_a, my_a2);
           }
           break;

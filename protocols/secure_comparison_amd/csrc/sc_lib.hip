@@ -297,6 +297,7 @@ struct Builder {
   void addt(uint32_t e) { touch(e); emit(OP_ADDT, 0, e); }
   void redc() { emit(OP_REDC); redcs++; }
   void storew(int ext, uint32_t off = 0) { emit(OP_STOREW, 0, 0, ext, off); }
+  void storew_at(int ext, int ext_index) { emit(OP_STOREW, 0, 0, ext, 0, 1 + ext_index); }   // row = ext_index[item] (u64)
   void storel(int ext, uint32_t off = 0) { emit(OP_STOREL, 0, 0, ext, off); }
   void storeflag(int ext, uint32_t off, int lds_const) { emit(OP_STOREFLAG, 0, 0, ext, off, lds_const); }
   void end() { emit(OP_END); }
@@ -871,8 +872,8 @@ int sc_fixedbase_pow(sc_ctx* ctx, int fbt, const uint32_t* e, int ewords, const 
   return run_vm(ctx, f.mod, it->second, ex, 3, count, f.d_rows);
 }
 
-int sc_modexp_var(sc_ctx* ctx, int mod, const uint32_t* x, const uint32_t* e, int ewords, int ebits, int fbt,
-                  const uint32_t* e2, int e2words, uint32_t* out, uint64_t count) {
+static int modexp_var_impl(sc_ctx* ctx, int mod, const uint32_t* x, const uint32_t* e, int ewords, int ebits, int fbt,
+                           const uint32_t* e2, int e2words, const uint64_t* dest, uint32_t* out, uint64_t count) {
   if (ctx && count == 0) return SC_OK;  // empty batch: nothing to do (pointers may be null)
   if (!valid_mod(ctx, mod) || !x || !e || !out || ewords <= 0 || ebits <= 0 || ebits > 32 * ewords)
     return fail(ctx, SC_ERR_ARG, "sc_modexp_var: bad argument");
@@ -882,7 +883,7 @@ int sc_modexp_var(sc_ctx* ctx, int mod, const uint32_t* x, const uint32_t* e, in
     if (fbt >= (int)ctx->fbts.size() || ctx->fbts[fbt].mod != mod || !e2 || e2words <= 0) return fail(ctx, SC_ERR_ARG, "sc_modexp_var: bad fixed-base table");
     f = &ctx->fbts[fbt];
   }
-  std::string key = "mvar:" + std::to_string(mod) + ":" + std::to_string(ebits) + ":" + std::to_string(fbt);
+  std::string key = "mvar:" + std::to_string(mod) + ":" + std::to_string(ebits) + ":" + std::to_string(fbt) + (dest ? ":s" : "");
   auto it = ctx->progs.find(key);
   if (it == ctx->progs.end()) {
     const int w = ebits <= 4 ? 1 : (ebits <= 12 ? 2 : 3);
@@ -894,13 +895,27 @@ int sc_modexp_var(sc_ctx* ctx, int mod, const uint32_t* x, const uint32_t* e, in
     bd.loadt_tbldig(1, (nd - 1) * w, w, 0);
     for (int d = nd - 2; d >= 0; d--) { for (int k = 0; k < w; k++) bd.sqr(); bd.mul_tbldig(1, d * w, w, 0); }
     if (f) for (int j = 0; j < f->nwin; j++) bd.mul_fbt(3, j * f->window, f->window, j);
-    bd.redc(); bd.storew(2); bd.end();
+    bd.redc();
+    if (dest) bd.storew_at(2, 4); else bd.storew(2);
+    bd.end();
     Prog p; int rc = finalize_prog(ctx, m, bd, &p); if (rc) return rc;
     it = ctx->progs.emplace(key, p).first;
   }
-  VmExt ex[4] = {mk_ext(x, m.nwords, m.nwords), mk_ext(e, ewords, ewords), mk_ext(out, m.nwords, m.nwords),
-                 mk_ext(e2, e2words, e2words)};
-  return run_vm(ctx, mod, it->second, ex, 4, count, f ? f->d_rows : nullptr);
+  // a scattered store never leaves the output array: rows >= count are dropped by the limit of the output operand
+  VmExt ex[5] = {mk_ext(x, m.nwords, m.nwords), mk_ext(e, ewords, ewords), mk_ext(out, m.nwords, m.nwords, dest ? count : ~0ull),
+                 mk_ext(e2, e2words, e2words), mk_ext(dest, 2, 2)};
+  return run_vm(ctx, mod, it->second, ex, 5, count, f ? f->d_rows : nullptr);
+}
+
+int sc_modexp_var(sc_ctx* ctx, int mod, const uint32_t* x, const uint32_t* e, int ewords, int ebits, int fbt,
+                  const uint32_t* e2, int e2words, uint32_t* out, uint64_t count) {
+  return modexp_var_impl(ctx, mod, x, e, ewords, ebits, fbt, e2, e2words, nullptr, out, count);
+}
+
+int sc_modexp_var_scatter(sc_ctx* ctx, int mod, const uint32_t* x, const uint32_t* e, int ewords, int ebits, int fbt,
+                          const uint32_t* e2, int e2words, const uint64_t* dest_index, uint32_t* out, uint64_t count) {
+  if (ctx && count != 0 && !dest_index) return fail(ctx, SC_ERR_ARG, "sc_modexp_var_scatter: no destination index");
+  return modexp_var_impl(ctx, mod, x, e, ewords, ebits, fbt, e2, e2words, dest_index, out, count);
 }
 
 static int paillier_encrypt_raw_impl(sc_ctx* ctx, int mod_n2, int cst_n, const uint32_t* mwords, int m_words, uint32_t* out, uint64_t count, bool negate);

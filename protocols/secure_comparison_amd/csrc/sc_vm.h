@@ -16,7 +16,7 @@ enum VmOpcode : uint32_t {
   OP_ADDW = 3,       // ACC += words (same addressing as LOADW), lazy limb-wise add
   OP_LOADT = 4,      // ACC = limb-form operand given by akind (table / const / fbt / ext-limbs)
   OP_REDC = 5,       // ACC = ACC / R mod n
-  OP_STOREW = 6,     // canonical(ACC) -> words ext[w1] at off w2
+  OP_STOREW = 6,     // canonical(ACC) -> words ext[w1] at off w2; w3 != 0: at the flat item index ext[w3-1][item] (u64) instead
   OP_STOREFLAG = 7,  // (canonical(ACC) == const[w3]) -> u8 ext[w1] at off w2
   OP_STT = 8,        // scratch[imm] = ACC
   OP_ADD1 = 9,       // ACC += 1 (lazy)

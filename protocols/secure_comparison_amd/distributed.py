@@ -34,3 +34,17 @@ def all_gather_results(local: torch.Tensor, total: int, group=None) -> torch.Ten
     for p, full in zip(parts, padded):
         p.copy_(full[: p.shape[0]])
     return torch.cat(parts, dim=0)
+
+
+def all_gather_planes(local: torch.Tensor, group=None) -> torch.Tensor:
+    """Gather a bit-major per-bit vector (the wire batch [c_i] or [d],[beta_i]: [planes][B_r][words] on rank r) into the
+    BLOCKED global layout [rank][planes][B_r][words] of SURVEY 8(e): every rank's block is one contiguous piece, so a single
+    all-gather fills it and no transpose follows; comparison b of rank r, plane i is `out[r, i, b]`.  Equal shard sizes only
+    (pad the last shard otherwise: a ragged wire batch has no single rectangular layout)."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return local.reshape((1,) + tuple(local.shape))
+    out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    # (the collective wants the ranks concatenated along the first axis; the blocked layout is that very memory)
+    dist.all_gather_into_tensor(out.view((world * local.shape[0],) + tuple(local.shape[1:])), local.contiguous(), group=group)
+    return out

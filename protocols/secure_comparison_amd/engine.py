@@ -270,16 +270,24 @@ class Engine:
         return out
 
     def modexp_var(self, mod: Modulus, x: torch.Tensor, e: torch.Tensor, ebits: int, fb: FixedBase | None = None,
-                   e2: torch.Tensor | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
+                   e2: torch.Tensor | None = None, out: torch.Tensor | None = None, dest: torch.Tensor | None = None) -> torch.Tensor:
+        """x[i]^e[i] [* base^e2[i]]; with `dest` (int64 [count]) the result of item i lands in row dest[i] (a permutation)."""
         count = self._items(x)
         self._arr(x, "x", count, mod.nwords)
         self._arr(e, "e", count)
         self._arr(e2, "e2", count, optional=fb is None)
         out = self._out(out, count, mod.nwords)
         self._sync_stream()
-        self._check(self.lib.sc_modexp_var(self.ctx, mod.id, self._ptr(x), self._ptr(e), e.shape[-1], ebits,
-                                           -1 if fb is None else fb.id, self._ptr(e2), 0 if e2 is None else e2.shape[-1],
-                                           self._ptr(out), count))
+        fbid, e2w = (-1 if fb is None else fb.id), (0 if e2 is None else e2.shape[-1])
+        if dest is None:
+            self._check(self.lib.sc_modexp_var(self.ctx, mod.id, self._ptr(x), self._ptr(e), e.shape[-1], ebits, fbid, self._ptr(e2), e2w,
+                                               self._ptr(out), count))
+        else:
+            self._arr(dest, "dest", dtype=torch.int64)
+            if dest.numel() != count:
+                raise ValueError(f"dest: {dest.numel()} items, expected {count}")
+            self._check(self.lib.sc_modexp_var_scatter(self.ctx, mod.id, self._ptr(x), self._ptr(e), e.shape[-1], ebits, fbid, self._ptr(e2), e2w,
+                                                       self._ptr(dest), self._ptr(out), count))
         return out
 
     def modinv(self, mod: Modulus, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:

@@ -280,10 +280,15 @@ class Initiator:
                             scheme_dgk: DGK) -> torch.Tensor:
         """Steps 4c, 4d, 4e, 4f, 4h fused for B comparisons.  beta_is_enc: [l][B][nw] bit-major; d_enc: [B][nw];
         delta_a: [B] u64 (step 4g's draw, injected).  Returns [l+1][B][nw] = c_-1, c_0, .., c_{l-1} (not blinded)."""
+        from ._views import cat_rows
+
         e = scheme_dgk.engine
         l, count, nw = beta_is_enc.shape
-        inv = scheme_dgk.neg_batch(torch.cat([beta_is_enc.reshape(l * count, nw), d_enc], dim=0))
-        beta_inv, d_inv = inv[: l * count].reshape(l, count, nw), inv[l * count:]
+        # one inversion pass over [d], [beta_0] .. [beta_{l-1}]: a view when they arrive as the planes of one array (the
+        # batch driver's case), a copy when they came as two messages
+        planes = cat_rows([d_enc.reshape(1, count, nw), beta_is_enc])
+        inv = scheme_dgk.neg_batch(planes.reshape((l + 1) * count, nw))
+        d_inv, beta_inv = inv[:count], inv[count:].reshape(l, count, nw)
         pk = scheme_dgk.public_key
         return e.dgk_step4(scheme_dgk.mod_n, pk.g, scheme_dgk.g_inv, l, beta_is_enc, beta_inv, d_enc, d_inv, plain.alpha,
                            plain.alpha_tilde, plain.r_small, delta_a)
@@ -297,14 +302,21 @@ class Initiator:
         e = scheme_dgk.engine
         lp1, count, nw = c_is_enc.shape
         ubits = (scheme_dgk.public_key.u - 1).bit_length()
+        dest = None
+        if permutation is not None:
+            # the shuffle rides in the store of the blinding launch: blinded plane j of comparison b goes to output plane
+            # k with permutation[b][k] == j, i.e. to flat row inverse[b][j] * B + b
+            if tuple(permutation.shape) != (count, lp1) or permutation.dtype != torch.int64:
+                raise ValueError(f"permutation: expected int64 [{count}][{lp1}], got {permutation.dtype} {tuple(permutation.shape)}")
+            if bool(((permutation < 0) | (permutation >= lp1)).any()):
+                raise ValueError("permutation: entries outside range(l + 1)")
+            planes = torch.arange(lp1, device=permutation.device, dtype=torch.int64).expand(count, lp1)
+            inverse = torch.empty_like(permutation).scatter_(1, permutation, planes)
+            dest = (inverse.t() * count + torch.arange(count, device=permutation.device, dtype=torch.int64)).reshape(-1).contiguous()
         flat = e.modexp_var(scheme_dgk.mod_n, c_is_enc.reshape(lp1 * count, nw), rhos.reshape(lp1 * count, -1), ubits,
                             scheme_dgk.fb_h if randomizer_exponents is not None else None,
-                            None if randomizer_exponents is None else randomizer_exponents.reshape(lp1 * count, -1))
-        out = flat.reshape(lp1, count, nw)
-        if permutation is not None:
-            idx = permutation.t().reshape(lp1, count, 1).expand(lp1, count, nw)
-            out = torch.gather(out, 0, idx)
-        return out
+                            None if randomizer_exponents is None else randomizer_exponents.reshape(lp1 * count, -1), dest=dest)
+        return flat.reshape(lp1, count, nw)
 
     @staticmethod
     def step_6_batch(delta_a: torch.Tensor, delta_b_enc: torch.Tensor, scheme_paillier: Paillier) -> torch.Tensor:

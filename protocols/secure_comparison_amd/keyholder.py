@@ -104,14 +104,18 @@ class KeyHolder:
         d_enc, beta_enc = KeyHolder.step_4a_4b_batch(plain, l, dgk, pai, None if draws is None else draws.r_bob_dgk)
         if draws is None:
             nw = d_enc.shape[-1]
-            rnd = dgk.randomize_from_pool_batch(torch.cat([d_enc.reshape(1, count, nw), beta_enc], dim=0).reshape((l + 1) * count, nw))
+            from ._views import cat_rows
+
+            rnd = dgk.randomize_from_pool_batch(cat_rows([d_enc.reshape(1, count, nw), beta_enc]).reshape((l + 1) * count, nw))
             rnd = rnd.reshape(l + 1, count, nw)
             d_enc, beta_enc = rnd[0].contiguous(), rnd[1:].contiguous()
         await self.communicator.send(self.other_party, wire.pack_many(d_enc, beta_enc), msg_id=f"step_4b_batch_session_{sid}")
         c_enc = wire.unpack_tensor(await self.communicator.recv(self.other_party, msg_id=f"step_4i_batch_session_{sid}"), dev)
         c_enc = wire.expect_array(c_enc, (l + 1, count, dgk.mod_n.nwords), "[c_i]")
         delta_b = KeyHolder.step_4j_batch(c_enc, dgk)
-        triple = torch.cat(KeyHolder.step_5_batch(plain, delta_b, pai), dim=0)
+        from ._views import cat_rows
+
+        triple = cat_rows(KeyHolder.step_5_batch(plain, delta_b, pai))
         if draws is None:
             triple = pai.randomize_from_pool_batch(triple)
         else:

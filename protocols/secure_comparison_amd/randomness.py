@@ -1,7 +1,8 @@
 """Host-side generation of the random inputs of a batch.
 
 `source="os"` draws from the operating system's CSPRNG (the reference uses `secrets`, SC/initiator.py:5);
-`source="torch"` uses a seeded device generator -- NOT cryptographic, for benchmarks and reproducible tests only."""
+`source="torch"` uses a seeded torch generator (on its own device) -- NOT cryptographic, for benchmarks and reproducible
+tests only; every helper here honours it, so boot_pools(source="torch", generator=g) is reproducible."""
 from __future__ import annotations
 
 import os
@@ -40,7 +41,11 @@ def uniform_below(n: int, count: int, device, source: str = "os", generator: tor
     while filled < count:
         need = count - filled
         draw = max(16, int(need * 2.2))
-        cand = random_bits(bits, (draw,), "cpu", source if source == "os" else "os").numpy().view(np.uint32)
+        if source == "os":
+            cand = random_bits(bits, (draw,), "cpu", "os").numpy().view(np.uint32)
+        else:   # the seeded generator draws on its own device; the rejection step runs on the host
+            gdev = generator.device if generator is not None else "cpu"
+            cand = random_bits(bits, (draw,), gdev, "torch", generator).cpu().numpy().view(np.uint32)
         lt = np.zeros(draw, dtype=bool)
         eq = np.ones(draw, dtype=bool)
         for k in range(nw - 1, -1, -1):

@@ -579,9 +579,9 @@ class DGK(_Scheme):
     def encrypt_bits_batch(self, bits: torch.Tensor) -> torch.Tensor:
         """g^b for b in {0,1}: words [count][nw] (SC/keyholder.py:213, 231)."""
         e = self.engine
-        one = e.upload([1], self.mod_n.nwords)
-        gw = e.upload([self.public_key.g], self.mod_n.nwords)
-        return torch.where((bits != 0).reshape(-1, 1), gw, one).contiguous()
+        if getattr(self, "_bit_words", None) is None:      # [0] = g^0 = 1, [1] = g: uploaded once per scheme object
+            self._bit_words = e.upload([1, self.public_key.g], self.mod_n.nwords)
+        return self._bit_words[(bits != 0).reshape(-1).to(torch.int64)]
 
     def randomize_batch(self, c: torch.Tensor | None, r: torch.Tensor) -> torch.Tensor:
         """c * h^r mod n for exponent words r [count][ewords] (SC/keyholder.py:106-108; SC/initiator.py:153-154).

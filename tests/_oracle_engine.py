@@ -91,10 +91,15 @@ class OracleEngine:
             r = [a * b % fb.mod.n for a, b in zip(r, self._ints(mul_into))]
         return self.upload(r, fb.mod.nwords)
 
-    def modexp_var(self, mod, x, e, ebits, fb=None, e2=None, out=None):
+    def modexp_var(self, mod, x, e, ebits, fb=None, e2=None, out=None, dest=None):
         r = [pow(a, b, mod.n) for a, b in zip(self._ints(x), self._ints(e))]
         if fb is not None:
             r = [a * pow(fb.base, b, mod.n) % mod.n for a, b in zip(r, self._ints(e2))]
+        if dest is not None:
+            placed = [0] * len(r)
+            for i, d in enumerate(dest.tolist()):
+                placed[d] = r[i]
+            r = placed
         return self.upload(r, mod.nwords)
 
     def modinv(self, mod, x, out=None):

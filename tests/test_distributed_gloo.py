@@ -43,6 +43,14 @@ def _worker(rank, world, port, B, ret):
     local = secure_comparison_batch(eng.upload(x_enc[lo:hi], 2 * nw), eng.upload(y_enc[lo:hi], 2 * nw), L, bob_p.public_copy(),
                                     bob_d.public_copy(), bob_p, bob_d, draws)
     full = all_gather_results(local, B)
+    from protocols.secure_comparison_amd.distributed import all_gather_planes
+
+    if B % world == 0:   # the blocked wire-batch layout [rank][plane][b][words]
+        mine = torch.arange((L + 1) * (hi - lo) * 3, dtype=torch.int32).reshape(L + 1, hi - lo, 3) + 100000 * rank
+        blocked = all_gather_planes(mine)
+        assert blocked.shape == (world, L + 1, hi - lo, 3)
+        for r in range(world):
+            assert int(blocked[r, 0, 0, 0]) == 100000 * r and int(blocked[r, L, hi - lo - 1, 2]) == 100000 * r + (L + 1) * (hi - lo) * 3 - 1
     if rank == 0:
         expect = [o.compare(a, b, L, osk, od, d, True) for a, b, d in zip(x_enc, y_enc, drs)]
         ret["ok"] = eng.download(full) == expect and [osk.dec_raw(v) for v in expect] == [int(x <= y) for x, y in zip(xs, ys)]

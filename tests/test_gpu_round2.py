@@ -234,3 +234,46 @@ def test_onelane_whole_comparisons(onelane_engine, keys):
     eng.set_onelane_mode(0)
     assert eng.download(secure_comparison_batch(tx, ty, l, alice_p, alice_d, bob_p, bob_d, draws)) == expect
     assert [sk.dec_raw(c) for c in expect] == [int(x <= y) for x, y in zip(xs, ys)]
+
+
+def test_scattered_store_is_the_shuffle(engine, keys):
+    """sc_modexp_var_scatter: the result of item i lands in row dest[i] -- equal to computing in place and gathering; rows named
+    out of range are dropped (nothing is written outside the output array), and Initiator.step_4i_batch refuses permutations
+    that are not int64 [B][l+1] with entries in range."""
+    from protocols.secure_comparison_amd import DGK, Initiator
+
+    dgk = oracle_dgk(keys, "dgk_1024_l16")
+    rng = random.Random(3)
+    sch = DGK(dgk.n, dgk.g, dgk.h, dgk.u, dgk.t, engine=engine, randomizer_bits=400)
+    mod = sch.mod_n
+    count = 333
+    xs = [rng.randrange(1, dgk.n) for _ in range(count)]
+    es = [rng.randrange(1, dgk.u) for _ in range(count)]
+    perm = list(range(count))
+    rng.shuffle(perm)
+    tx, te = engine.upload(xs, mod.nwords), engine.upload(es, 1)
+    dest = torch.tensor(perm, dtype=torch.int64, device=engine.device)
+    got = engine.download(engine.modexp_var(mod, tx, te, 18, dest=dest))
+    expect = [None] * count
+    for i, d in enumerate(perm):
+        expect[d] = pow(xs[i], es[i], dgk.n)
+    assert got == expect
+    # out-of-range destinations: guard words around the output stay untouched
+    buf = torch.full((count + 2, mod.nwords), 0x5A5A5A5A, dtype=torch.int32, device=engine.device)
+    bad = dest.clone()
+    bad[7], bad[100] = count + 5, 1 << 40
+    engine.modexp_var(mod, tx, te, 18, out=buf[1:count + 1], dest=bad)
+    torch.cuda.synchronize()
+    assert bool((buf[0] == 0x5A5A5A5A).all()) and bool((buf[count + 1] == 0x5A5A5A5A).all())
+    # the protocol-level entry
+    l, B = 16, 9
+    c = engine.upload([rng.randrange(1, dgk.n) for _ in range((l + 1) * B)], mod.nwords).reshape(l + 1, B, mod.nwords)
+    rhos = engine.upload([rng.randrange(1, dgk.u) for _ in range((l + 1) * B)], 1).reshape(l + 1, B, 1)
+    pm = torch.stack([torch.randperm(l + 1) for _ in range(B)]).to(engine.device)
+    plain = Initiator.step_4i_batch(c, sch, rhos, None)
+    shuffled = Initiator.step_4i_batch(c, sch, rhos, pm)
+    idx = pm.t().reshape(l + 1, B, 1).expand(l + 1, B, mod.nwords)
+    assert torch.equal(shuffled, torch.gather(plain, 0, idx))
+    for wrong in (pm[:, :-1], pm.to(torch.int32), pm + 1, pm[:-1]):
+        with pytest.raises(ValueError):
+            Initiator.step_4i_batch(c, sch, rhos, wrong)
