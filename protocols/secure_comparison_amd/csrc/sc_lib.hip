@@ -18,6 +18,10 @@
 
 using namespace sc;
 
+#ifndef SC_INV_TOP
+#define SC_INV_TOP 2048
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -1000,7 +1004,9 @@ int sc_plain_bob(sc_ctx* ctx, const uint32_t* z, const uint32_t* n_hptr, int nw,
 // ------------------------------------------------------------------------------------------------
 static int modinv_rec(sc_ctx* ctx, int mod, const uint32_t* x, uint32_t* out, uint64_t count, int64_t* bad, int depth) {
   const Mod& m = ctx->mods[mod];
-  const uint64_t TOP = 48;
+  // residues inverted directly by the division-step kernel (one wave each, all of them resident at once: a few thousand cost
+  // the latency of one); below that the tree's levels -- two latency-bound launches each -- cost more than they save
+  const uint64_t TOP = SC_INV_TOP;
   if (count <= TOP) {
     int* d_status;
     { int rc0 = tmp_buf(ctx, TMP_XGCD_STATUS, sizeof(int) * count, (void**)&d_status); if (rc0) return rc0; }
