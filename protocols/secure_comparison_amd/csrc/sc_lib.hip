@@ -1002,7 +1002,14 @@ int sc_plain_bob(sc_ctx* ctx, const uint32_t* z, const uint32_t* n_hptr, int nw,
 // ------------------------------------------------------------------------------------------------
 // batch inversion: Montgomery's trick over strided chunks + on-device binary extended GCD at the top
 // ------------------------------------------------------------------------------------------------
-static int modinv_rec(sc_ctx* ctx, int mod, const uint32_t* x, uint32_t* out, uint64_t count, int64_t* bad, int depth) {
+// One level of the tree, kept for the error path: its operand array, chunk length and chunk count
+struct InvLevel { const uint32_t* x; uint64_t count; uint32_t K; uint64_t C; };
+struct InvPending { std::vector<InvLevel> levels; int* d_status = nullptr; uint64_t top_count = 0; };
+
+// Queues every launch of the inversion (up-sweeps, the division-step kernel at the top, down-sweeps) WITHOUT waiting for the top
+// kernel's verdict: the host reads the status words once, after everything is in the stream (sc_modinv), so the GPU never idles
+// on a host round trip in the middle of the tree.  A non-invertible element makes the results garbage; the caller reports it.
+static int modinv_rec(sc_ctx* ctx, int mod, const uint32_t* x, uint32_t* out, uint64_t count, InvPending* pend, int depth) {
   const Mod& m = ctx->mods[mod];
   // residues inverted directly by the division-step kernel (one wave each, all of them resident at once: a few thousand cost
   // the latency of one); below that the tree's levels -- two latency-bound launches each -- cost more than they save
@@ -1014,11 +1021,8 @@ static int modinv_rec(sc_ctx* ctx, int mod, const uint32_t* x, uint32_t* out, ui
     { int rc0 = device_n_half(ctx, m.n.data(), m.nwords, &d_nw); if (rc0) return rc0; }
     int rc = launch_xgcd(ctx->stream, x, out, d_nw, m.nwords, count, d_status);
     if (rc != 0) return fail(ctx, SC_ERR_HIP, "xgcd launch failed");
-    std::vector<int> st(count);
-    HIPCHK(ctx, hipMemcpyAsync(st.data(), d_status, sizeof(int) * count, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    for (uint64_t i = 0; i < count; i++)
-      if (st[i] != 1) { if (bad) *bad = (int64_t)i; return fail(ctx, SC_ERR_NOT_INVERTIBLE, "element %llu is not invertible", (unsigned long long)i); }
+    pend->d_status = d_status;
+    pend->top_count = count;
     return SC_OK;
   }
   // Chunk length: a chunk is one sequential chain of 3 (K - 1) products, so the tree's latency is the sum of the chunk lengths
@@ -1057,49 +1061,66 @@ static int modinv_rec(sc_ctx* ctx, int mod, const uint32_t* x, uint32_t* out, ui
     Prog p; int rc = finalize_prog(ctx, m, bd, &p); if (rc) return rc;
     it2 = ctx->progs.emplace(k2, p).first;
   }
+  pend->levels.push_back(InvLevel{x, count, K, C});
   int rc;
   {
     VmExt ex[3] = {mk_ext(x, m.nwords, m.nwords, count), mk_ext(d_P, m.S, 0, (uint64_t)K * C), mk_ext(d_tot, m.nwords, m.nwords)};
     rc = run_vm(ctx, mod, it1->second, ex, 3, C);
   }
-  int64_t bad_chunk = -1;
-  if (!rc) rc = modinv_rec(ctx, mod, d_tot, d_totinv, C, &bad_chunk, depth + 1);
+  if (!rc) rc = modinv_rec(ctx, mod, d_tot, d_totinv, C, pend, depth + 1);
   if (!rc) {
     VmExt ex[5] = {mk_ext(x, m.nwords, m.nwords, count), mk_ext(d_P, m.S, 0, (uint64_t)K * C), mk_ext(nullptr, 0, 0),
                    mk_ext(d_totinv, m.nwords, m.nwords), mk_ext(out, m.nwords, m.nwords, count)};
     rc = run_vm(ctx, mod, it2->second, ex, 5, C);
   }
-  if (rc == SC_ERR_NOT_INVERTIBLE && bad_chunk >= 0) {
-    // The product of chunk `bad_chunk` (members x[i C + bad_chunk], i < K) is not invertible: test its members one by one
-    // with the extended GCD and report the first that fails, like the reference's pow / gmpy2.invert name the operand.
-    uint64_t members = 0;
-    while (members < K && members * C + (uint64_t)bad_chunk < count) members++;
-    uint32_t* d_m = nullptr; int* d_status = nullptr; uint32_t* d_nw = nullptr;
-    { int rc0 = tmp_buf(ctx, TMP_INV_MEMBERS, (size_t)members * m.nwords * 4 * 2, (void**)&d_m); if (rc0) return rc0; }
-    { int rc0 = tmp_buf(ctx, TMP_XGCD_STATUS, sizeof(int) * members, (void**)&d_status); if (rc0) return rc0; }
-    { int rc0 = device_n_half(ctx, m.n.data(), m.nwords, &d_nw); if (rc0) return rc0; }
-    HIPCHK(ctx, hipMemcpy2DAsync(d_m, (size_t)m.nwords * 4, x + (size_t)bad_chunk * m.nwords, (size_t)C * m.nwords * 4,
-                                 (size_t)m.nwords * 4, members, hipMemcpyDeviceToDevice, ctx->stream));
-    if (launch_xgcd(ctx->stream, d_m, d_m + (size_t)members * m.nwords, d_nw, m.nwords, members, d_status) != 0)
-      return fail(ctx, SC_ERR_HIP, "xgcd launch failed");
-    std::vector<int> st(members);
-    HIPCHK(ctx, hipMemcpyAsync(st.data(), d_status, sizeof(int) * members, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    int64_t first = -1;
-    for (uint64_t i = 0; i < members && first < 0; i++) if (st[i] != 1) first = (int64_t)(i * C + (uint64_t)bad_chunk);
-    if (first < 0) return fail(ctx, SC_ERR_HIP, "sc_modinv: chunk %lld is not invertible but all of its members are", (long long)bad_chunk);
-    if (bad) *bad = first;
-    return fail(ctx, SC_ERR_NOT_INVERTIBLE, "element %lld is not invertible", (long long)first);
-  }
   return rc;
+}
+
+// The product of chunk `chunk` of a level (members x[i C + chunk], i < K) is not invertible: test its members one by one with the
+// division-step kernel and return the first that fails, like the reference's pow / gmpy2.invert name the operand.
+static int modinv_find_member(sc_ctx* ctx, const Mod& m, const InvLevel& lv, int64_t chunk, int64_t* out_index) {
+  uint64_t members = 0;
+  while (members < lv.K && members * lv.C + (uint64_t)chunk < lv.count) members++;
+  uint32_t* d_m = nullptr; int* d_status = nullptr; uint32_t* d_nw = nullptr;
+  { int rc0 = tmp_buf(ctx, TMP_INV_MEMBERS, (size_t)members * m.nwords * 4 * 2, (void**)&d_m); if (rc0) return rc0; }
+  { int rc0 = tmp_buf(ctx, TMP_XGCD_STATUS, sizeof(int) * members, (void**)&d_status); if (rc0) return rc0; }
+  { int rc0 = device_n_half(ctx, m.n.data(), m.nwords, &d_nw); if (rc0) return rc0; }
+  HIPCHK(ctx, hipMemcpy2DAsync(d_m, (size_t)m.nwords * 4, lv.x + (size_t)chunk * m.nwords, (size_t)lv.C * m.nwords * 4,
+                               (size_t)m.nwords * 4, members, hipMemcpyDeviceToDevice, ctx->stream));
+  if (launch_xgcd(ctx->stream, d_m, d_m + (size_t)members * m.nwords, d_nw, m.nwords, members, d_status) != 0)
+    return fail(ctx, SC_ERR_HIP, "xgcd launch failed");
+  std::vector<int> st(members);
+  HIPCHK(ctx, hipMemcpyAsync(st.data(), d_status, sizeof(int) * members, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  for (uint64_t i = 0; i < members; i++)
+    if (st[i] != 1) { *out_index = (int64_t)(i * lv.C + (uint64_t)chunk); return SC_OK; }
+  return fail(ctx, SC_ERR_HIP, "sc_modinv: chunk %lld is not invertible but all of its members are", (long long)chunk);
 }
 
 int sc_modinv(sc_ctx* ctx, int mod, const uint32_t* x, uint32_t* out, uint64_t count, int64_t* bad_index) {
   if (ctx && count == 0) return SC_OK;  // empty batch: nothing to do (pointers may be null)
   if (!valid_mod(ctx, mod) || !x || !out) return fail(ctx, SC_ERR_ARG, "sc_modinv: bad argument");
-  if (count == 0) return SC_OK;
   if (bad_index) *bad_index = -1;
-  return modinv_rec(ctx, mod, x, out, count, bad_index, 0);
+  InvPending pend;
+  int rc = modinv_rec(ctx, mod, x, out, count, &pend, 0);
+  if (rc) return rc;
+  // the one host round trip of the call: the verdicts of the top kernel, read after every launch has been queued
+  std::vector<int> st(pend.top_count);
+  HIPCHK(ctx, hipMemcpyAsync(st.data(), pend.d_status, sizeof(int) * pend.top_count, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  int64_t bad = -1;
+  for (uint64_t i = 0; i < pend.top_count && bad < 0; i++) if (st[i] != 1) bad = (int64_t)i;
+  if (bad < 0) return SC_OK;
+  // error path: `bad` indexes the deepest level's chunk products; walk back up, one member test per level
+  const Mod& m = ctx->mods[mod];
+  for (int lv = (int)pend.levels.size() - 1; lv >= 0; lv--) {
+    int64_t member = -1;
+    rc = modinv_find_member(ctx, m, pend.levels[lv], bad, &member);
+    if (rc) return rc;
+    bad = member;
+  }
+  if (bad_index) *bad_index = bad;
+  return fail(ctx, SC_ERR_NOT_INVERTIBLE, "element %lld is not invertible", (long long)bad);
 }
 
 int sc_dgk_step4(sc_ctx* ctx, int mod, int cst_g, int cst_ginv, int l, const uint32_t* beta, const uint32_t* beta_inv,

@@ -6,7 +6,7 @@ res = {l: [] for l in libs}
 for rep in range(3):
     for l in libs:
         env = dict(os.environ, SC_AMD_LIB=os.path.abspath(l))
-        cp = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--steps", "2"], env=env, capture_output=True, text=True)
+        cp = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-extras", "--steps", "5", "--warmup", "2"] + os.environ.get("AB_ARGS", "").split(), env=env, capture_output=True, text=True)
         d = json.loads(cp.stdout.strip().splitlines()[-1])
         res[l].append(d["value"])
         print(os.path.basename(l), rep, f"{d['value']:.0f}", f"{d['roofline']['launch_ms']:.2f} ms", flush=True)
