@@ -110,6 +110,11 @@ int sc_mod_supports_sq(sc_ctx* ctx, int mod);
 /* flags[i] = (x[i]^e mod n == 1): DGK.is_zero, SC/keyholder.py:249 (e = v_p, n = p). */
 int sc_modexp_shared_isone(sc_ctx* ctx, int mod, int exp, const uint32_t* x_dptr, int x_words,
                            uint8_t* flags_dptr, uint64_t count);
+/* any_flags[b] = OR over the planes i of (x[i * inner + b]^e mod n == 1), b < inner, count = planes * inner items (bit-major):
+ * the whole of KeyHolder.step_4j -- delta_B = any(is_zero(c_i)) (SC/keyholder.py:246-253) -- in the zero-test launch itself
+ * (uint64 per comparison, 0 or 1; the array is cleared first). */
+int sc_modexp_shared_isone_any(sc_ctx* ctx, int mod, int exp, const uint32_t* x_dptr, int x_words, uint64_t inner,
+                               uint64_t* any_flags_dptr, uint64_t count);
 /* out[i] = base^e[i] mod n [* mul_into[i]] with the fixed-base table: DGK randomize / encrypt
  * g^m h^r (SC/keyholder.py:106-108, 213, 231; SC/initiator.py:153-154). e: [count][ewords]. */
 int sc_fixedbase_pow(sc_ctx* ctx, int fbt, const uint32_t* e_dptr, int ewords,

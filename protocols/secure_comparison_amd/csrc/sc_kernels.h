@@ -192,7 +192,13 @@ __global__ void __launch_bounds__(64, (G == 1 && L == 37) ? 2 : ((L > 18 || (G =
           const bool eq = gp.equal(acc, ref);
           const VmExt& e = args.ext[op.w1 & 0xf];
           const uint64_t flat = (uint64_t)op.w2 * args.count + idx;
-          if (live && gp.j == 0 && flat < e.limit) ((uint8_t*)e.ptr)[flat] = eq ? 1 : 0;
+          if (imm) {
+            // item (plane, b) = plane * inner + b: the flags of all planes of b are OR-ed into one u64 (zeroed by the host);
+            // hits are rare (at most one plane per comparison), so the atomic costs nothing
+            if (live && gp.j == 0 && eq) atomicOr((unsigned long long*)e.ptr + (idx % e.limit), 1ull);
+          } else if (live && gp.j == 0 && flat < e.limit) {
+            ((uint8_t*)e.ptr)[flat] = eq ? 1 : 0;
+          }
           break;
         }
         case OP_STT: {

@@ -743,14 +743,18 @@ int sc_modmul_const(sc_ctx* ctx, int mod, const uint32_t* a, int cst, uint32_t* 
 static int onelane_for(sc_ctx* ctx, int mod, uint64_t count);
 
 static int modexp_shared_impl(sc_ctx* ctx, int mod, int exp, const uint32_t* x, int x_words, const uint32_t* mul_into,
-                              uint32_t* out, uint8_t* flags, uint64_t count) {
+                              uint32_t* out, uint8_t* flags, uint64_t count, uint64_t* any_flags = nullptr, uint64_t inner = 0) {
   if (ctx && count == 0) return SC_OK;  // empty batch: nothing to do (pointers may be null)
-  if (!valid_mod(ctx, mod) || exp < 0 || exp >= (int)ctx->exps.size() || !x || (!out && !flags))
+  if (!valid_mod(ctx, mod) || exp < 0 || exp >= (int)ctx->exps.size() || !x || (!out && !flags && !any_flags))
     return fail(ctx, SC_ERR_ARG, "sc_modexp_shared: bad argument");
+  if (any_flags) {
+    if (inner == 0 || count % inner != 0) return fail(ctx, SC_ERR_ARG, "sc_modexp_shared_isone_any: count must be a multiple of the inner count");
+    HIPCHK(ctx, hipMemsetAsync(any_flags, 0, inner * sizeof(uint64_t), ctx->stream));
+  }
   if (ctx->exps[exp].bits > 64) mod = onelane_for(ctx, mod, count);   // long exponentiations of a chip-filling batch: one-lane twin
   const Mod& m = ctx->mods[mod];
   if (x_words <= 0) x_words = m.nwords;
-  const int mode = flags ? 2 : (mul_into ? 1 : 0);
+  const int mode = any_flags ? 3 : (flags ? 2 : (mul_into ? 1 : 0));
   std::string key = "mexp:" + std::to_string(mod) + ":" + std::to_string(exp) + ":" + std::to_string(x_words) + ":" + std::to_string(mode);
   auto it = ctx->progs.find(key);
   if (it == ctx->progs.end()) {
@@ -765,12 +769,14 @@ static int modexp_shared_impl(sc_ctx* ctx, int mod, int exp, const uint32_t* x, 
     emit_pow_shared(bd, ctx->exps[exp]);
     if (mode == 0) { bd.redc(); bd.storew(1); }
     else if (mode == 1) { bd.mul_extw(2); bd.storew(1); }
-    else { bd.storeflag(1, 0, 1); }    // compare with R mod n (Montgomery one)
+    else if (mode == 2) { bd.storeflag(1, 0, 1); }    // compare with R mod n (Montgomery one)
+    else { bd.emit(OP_STOREFLAG, 0, 1, 1, 0, 1); }    // ... and OR the verdict into the item's group flag
     bd.end();
     Prog p; int rc = finalize_prog(ctx, m, bd, &p); if (rc) return rc;
     it = ctx->progs.emplace(key, p).first;
   }
-  VmExt ex[3] = {mk_ext(x, x_words, x_words), flags ? mk_ext(flags, 0, 0) : mk_ext(out, m.nwords, m.nwords),
+  VmExt ex[3] = {mk_ext(x, x_words, x_words),
+                 any_flags ? mk_ext(any_flags, 0, 0, inner) : (flags ? mk_ext(flags, 0, 0) : mk_ext(out, m.nwords, m.nwords)),
                  mk_ext(mul_into, m.nwords, m.nwords)};
   return run_vm(ctx, mod, it->second, ex, 3, count);
 }
@@ -780,6 +786,12 @@ int sc_modexp_shared(sc_ctx* ctx, int mod, int exp, const uint32_t* x, int x_wor
 }
 int sc_modexp_shared_isone(sc_ctx* ctx, int mod, int exp, const uint32_t* x, int x_words, uint8_t* flags, uint64_t count) {
   return modexp_shared_impl(ctx, mod, exp, x, x_words, nullptr, nullptr, flags, count);
+}
+int sc_modexp_shared_isone_any(sc_ctx* ctx, int mod, int exp, const uint32_t* x, int x_words, uint64_t inner, uint64_t* any_flags,
+                               uint64_t count) {
+  if (ctx && count == 0) return SC_OK;
+  if (!any_flags) return fail(ctx, SC_ERR_ARG, "sc_modexp_shared_isone_any: no output");
+  return modexp_shared_impl(ctx, mod, exp, x, x_words, nullptr, nullptr, nullptr, count, any_flags, inner);
 }
 
 int sc_fbt_create(sc_ctx* ctx, int mod, const uint32_t* base_hptr, int exp_bits, int window, int* out_fbt) {

@@ -17,7 +17,8 @@ enum VmOpcode : uint32_t {
   OP_LOADT = 4,      // ACC = limb-form operand given by akind (table / const / fbt / ext-limbs)
   OP_REDC = 5,       // ACC = ACC / R mod n
   OP_STOREW = 6,     // canonical(ACC) -> words ext[w1] at off w2; w3 != 0: at the flat item index ext[w3-1][item] (u64) instead
-  OP_STOREFLAG = 7,  // (canonical(ACC) == const[w3]) -> u8 ext[w1] at off w2
+  OP_STOREFLAG = 7,  // (canonical(ACC) == const[w3]) -> u8 ext[w1] at off w2;  imm != 0: OR the flag into the u64 ext[w1][item mod ext.stride64]
+                     //   instead (ext.limit = inner count): one flag per group of items, e.g. delta_B = OR over the l+1 zero tests
   OP_STT = 8,        // scratch[imm] = ACC
   OP_ADD1 = 9,       // ACC += 1 (lazy)
   OP_SUB1 = 10,      // ACC = (ACC - 1) mod R, exact limbs

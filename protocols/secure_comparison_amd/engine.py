@@ -258,6 +258,18 @@ class Engine:
                                                     self._ptr(flags), count))
         return flags
 
+    def modexp_shared_isone_any(self, mod: Modulus, x: torch.Tensor, e: int, inner: int) -> torch.Tensor:
+        """int64 [inner]: OR over the planes i of (x[i * inner + b]^e == 1) -- x is bit-major [planes * inner][words]."""
+        count = self._items(x)
+        self._arr(x, "x", count)
+        if inner <= 0 or count % inner:
+            raise ValueError(f"x: {count} items are not a whole number of planes of {inner}")
+        out = torch.empty((inner,), dtype=torch.int64, device=self.device)
+        self._sync_stream()
+        self._check(self.lib.sc_modexp_shared_isone_any(self.ctx, mod.id, self.exponent(e), self._ptr(x), x.shape[-1], inner,
+                                                        self._ptr(out), count))
+        return out
+
     def fixedbase_pow(self, fb: FixedBase, e: torch.Tensor, mul_into: torch.Tensor | None = None,
                       out: torch.Tensor | None = None) -> torch.Tensor:
         count = self._items(e)

@@ -202,9 +202,7 @@ class KeyHolder:
     @staticmethod
     def step_4j_batch(c_is_enc: torch.Tensor, scheme_dgk: DGK) -> torch.Tensor:
         """delta_B per comparison: OR over the bit axis of the zero tests.  c_is_enc: [l+1][B][nw] -> [B] u64."""
-        lp1, count, nw = c_is_enc.shape
-        flags = scheme_dgk.is_zero_batch(c_is_enc.reshape(lp1 * count, nw)).reshape(lp1, count)
-        return (flags != 0).any(dim=0).to(torch.int64)
+        return scheme_dgk.any_zero_batch(c_is_enc)     # the OR over the bit axis happens in the zero-test launch
 
     @staticmethod
     def step_5_batch(plain: BobPlain, delta_b: torch.Tensor, scheme_paillier: Paillier) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:

@@ -624,6 +624,11 @@ class DGK(_Scheme):
         """uint8 flags: plaintext == 0 mod u (SC/keyholder.py:249)."""
         return self.engine.modexp_shared_isone(self.mod_p, c, self.secret_key.v_p)
 
+    def any_zero_batch(self, c: torch.Tensor) -> torch.Tensor:
+        """int64 [B]: 1 where some plane of the bit-major vector c [planes][B][nw] decrypts to 0 mod u (KeyHolder.step_4j)."""
+        planes, count, nw = c.shape
+        return self.engine.modexp_shared_isone_any(self.mod_p, c.reshape(planes * count, nw), self.secret_key.v_p, count)
+
     def neg_batch(self, c: torch.Tensor) -> torch.Tensor:
         return self.engine.modinv(self.mod_n, c)
 

@@ -85,6 +85,10 @@ class OracleEngine:
     def modexp_shared_isone(self, mod, x, e):
         return torch.tensor([int(pow(v, e, mod.n) == 1) for v in self._ints(x)], dtype=torch.uint8)
 
+    def modexp_shared_isone_any(self, mod, x, e, inner):
+        flags = [int(pow(v, e, mod.n) == 1) for v in self._ints(x)]
+        return torch.tensor([int(any(flags[b::inner])) for b in range(inner)], dtype=torch.int64)
+
     def fixedbase_pow(self, fb, e, mul_into=None, out=None):
         r = [pow(fb.base, v, fb.mod.n) for v in self._ints(e)]
         if mul_into is not None:

@@ -277,3 +277,28 @@ def test_scattered_store_is_the_shuffle(engine, keys):
     for wrong in (pm[:, :-1], pm.to(torch.int32), pm + 1, pm[:-1]):
         with pytest.raises(ValueError):
             Initiator.step_4i_batch(c, sch, rhos, wrong)
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_fused_any_zero_equals_or_of_zero_tests(engine, keys, mode):
+    """sc_modexp_shared_isone_any (delta_B in the zero-test launch) against the per-item flags OR-ed on the host side, with
+    zero plaintexts planted in known planes, ragged batch, both kernel policies for the 1024-bit prime."""
+    from protocols.secure_comparison_amd import DGK
+
+    dgk = oracle_dgk(keys, "dgk_2048_l32")
+    sch = DGK(dgk.n, dgk.g, dgk.h, dgk.u, dgk.t, dgk.p, dgk.q, dgk.v_p, dgk.v_q, engine=engine, randomizer_bits=400)
+    rng = random.Random(44)
+    planes, B = 33, 77
+    ms = [[rng.randrange(1, dgk.u) for _ in range(B)] for _ in range(planes)]
+    for b in (0, 5, 76):
+        ms[rng.randrange(planes)][b] = 0
+    ms[3][40] = ms[20][40] = 0                                   # two zero planes in one comparison
+    c = torch.stack([engine.upload([dgk.randomize(dgk.enc_raw(m), rng.getrandbits(400)) for m in row], sch.mod_n.nwords) for row in ms])
+    engine.set_onelane_mode(mode)
+    try:
+        got = sch.any_zero_batch(c).tolist()
+        flags = sch.is_zero_batch(c.reshape(planes * B, -1)).reshape(planes, B)
+    finally:
+        engine.set_onelane_mode(1)
+    expect = [int(any(ms[i][b] == 0 for i in range(planes))) for b in range(B)]
+    assert got == expect == (flags != 0).any(dim=0).to(torch.int64).tolist() and sum(expect) == 4
