@@ -15,8 +15,12 @@ namespace sc {
 // The micro-op interpreter.  One 64-lane workgroup (= one wave) processes 64/G items per pass of
 // the program and grid-strides over the batch.
 // ---------------------------------------------------------------------------------------------
+#ifndef SC_L27_WAVES
+#define SC_L27_WAVES 2    // waves per SIMD of the L = 27 configurations (1536 / 3072 / 6144-bit moduli): 256 VGPRs, the 120 spill
+                          // instructions all outside the product loops; +2 % on configs[4] with 3072-bit DGK over one wave + AGPR copies
+#endif
 template <int G, int L, int WB>
-__global__ void __launch_bounds__(64, (G == 1 && L == 37) ? 2 : ((L > 18 || (G == 16 && L > 14)) ? 1 : SC_VM_WAVES)) k_vm(const VmArgs args) {
+__global__ void __launch_bounds__(64, (G == 1 && L == 37) ? 2 : (L == 27 ? SC_L27_WAVES : ((L > 18 || (G == 16 && L > 14)) ? 1 : SC_VM_WAVES))) k_vm(const VmArgs args) {
   using GT = Grp<G, L, WB>;
   constexpr int S = GT::S, NG = GT::NG, SP = GT::SP, WP = GT::WP;
   __shared__ uint32_t s_a[NG * SP];            // per-group staging area for the LDS-side operand

@@ -17,6 +17,7 @@ SIZES = [40, 64, 127, 256, 500, 514, 1024, 1030, 1536, 1550, 1600, 2048, 2060, 3
 # the largest moduli each configuration accepts (capacity 29 G L minus the 8 guard bits) and their neighbours
 CAPS = [522, 1044, 1566, 1624, 2088, 3132, 3248, 4176, 6264, 6496, 8352]
 SIZES += [c - d for c in CAPS for d in (8, 9, 31, 33)]
+SIZES += [1000, 1020, 1024, 1024, 1027, 1028, 1029]   # around the one-lane configuration's capacity (28 * 37 - 8 bits)
 
 
 def pattern(rng, bits):
@@ -37,6 +38,7 @@ def one_round(eng, rng):
     bits = rng.choice(SIZES) if rng.random() < 0.7 else rng.randrange(40, 8300)
     n = pattern(rng, bits)
     eng.set_latency_mode(rng.choice([0, 1, 2]))
+    eng.set_onelane_mode(rng.choice([0, 1, 2, 2]))      # the one-lane (1, 37) kernels forced on for the moduli they fit
     try:
         mod = eng.modulus(n)
     except Exception as exc:                                         # larger than the largest configuration
