@@ -308,10 +308,10 @@ class Initiator:
             # k with permutation[b][k] == j, i.e. to flat row inverse[b][j] * B + b
             if tuple(permutation.shape) != (count, lp1) or permutation.dtype != torch.int64:
                 raise ValueError(f"permutation: expected int64 [{count}][{lp1}], got {permutation.dtype} {tuple(permutation.shape)}")
-            if bool(((permutation < 0) | (permutation >= lp1)).any()):
-                raise ValueError("permutation: entries outside range(l + 1)")
+            # entries are clamped into range instead of checked (a check would cost a host round trip in the middle of the step);
+            # a row that is not a permutation only scrambles that comparison's own vector -- the store never leaves the array
             planes = torch.arange(lp1, device=permutation.device, dtype=torch.int64).expand(count, lp1)
-            inverse = torch.empty_like(permutation).scatter_(1, permutation, planes)
+            inverse = torch.zeros_like(permutation).scatter_(1, permutation.clamp(0, lp1 - 1), planes)
             dest = (inverse.t() * count + torch.arange(count, device=permutation.device, dtype=torch.int64)).reshape(-1).contiguous()
         flat = e.modexp_var(scheme_dgk.mod_n, c_is_enc.reshape(lp1 * count, nw), rhos.reshape(lp1 * count, -1), ubits,
                             scheme_dgk.fb_h if randomizer_exponents is not None else None,
