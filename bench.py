@@ -151,6 +151,7 @@ def parse_args(argv=None):
     ap.add_argument("--streams", type=int, default=0, help="concurrent shards per GPU (one library context, HIP stream and host thread each); 1 = a single stream; "
                     "0 = automatic: 2 from 65536 comparisons per GPU")
     ap.add_argument("--latency-mode", type=int, default=1, help="small-batch kernel policy (sc_ctx_set_latency_mode): 0 never, 1 automatic, 2 always")
+    ap.add_argument("--onelane-mode", type=int, default=1, help="large-batch kernel policy for the 1024-bit primes (sc_ctx_set_onelane_mode): 0 never, 1 automatic, 2 always")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0)
     ap.add_argument("--no-extras", action="store_true", help="skip the informational legs (window sensitivity, online phase, PCIe-inclusive)")
@@ -204,6 +205,7 @@ def main() -> None:
     engines = [eng] + [Engine() for _ in range(1, ns)]
     for e_ in engines:
         e_.set_latency_mode(args.latency_mode)
+        e_.set_onelane_mode(args.onelane_mode)
 
     def build_parties(window: int) -> tuple[list[PartySet], float, int]:
         """Both parties' scheme objects per shard context.  The fixed-base tables are built once (first context) and shared

@@ -59,6 +59,10 @@ int sc_ctx_set_latency_mode(sc_ctx* ctx, int mode);
  * registers: 1.25x the rate per number, but 64 numbers per wave (exponents of more than 64 bits only).  mode 0: never; 1 (default): from one and a half rounds of the
  * chip's resident waves (196608 numbers on 256 CUs); 2: whenever the modulus fits (tests).  Results are the same canonical residues in every mode. */
 int sc_ctx_set_onelane_mode(sc_ctx* ctx, int mode);
+/* Tell the context that `contexts` library contexts (this one included) work on its GPU at the same time -- the concurrent
+ * shards of one batch, each on its own stream.  Batch-size policies then count rounds of 1/contexts of the chip (a launch that
+ * under-fills the whole chip is not alone on it).  Default 1. */
+int sc_ctx_set_chip_share(sc_ctx* ctx, int contexts);
 
 /* device memory helpers for callers that do not bring their own allocator */
 int sc_malloc(sc_ctx* ctx, size_t bytes, void** out_dptr);

@@ -14,7 +14,7 @@ SYMBOLS = [
     "sc_mod_create", "sc_mod_words", "sc_exp_create", "sc_const_create", "sc_fbt_create", "sc_fbt_import", "sc_fbt_bytes",
     "sc_modmul", "sc_modmul_const", "sc_modexp_shared", "sc_modexp_shared_sq", "sc_mod_supports_sq", "sc_modexp_shared_isone", "sc_modexp_shared_isone_any", "sc_fixedbase_pow", "sc_modexp_var", "sc_modexp_var_scatter",
     "sc_modinv", "sc_paillier_encrypt_raw", "sc_paillier_encrypt_raw_neg", "sc_paillier_l_mul", "sc_crt_combine", "sc_plain_alice", "sc_plain_bob", "sc_dgk_step4",
-    "sc_peak_probe", "sc_mac_counter", "sc_table_traffic_probe", "sc_ctx_set_latency_mode", "sc_ctx_set_onelane_mode",
+    "sc_peak_probe", "sc_mac_counter", "sc_table_traffic_probe", "sc_ctx_set_latency_mode", "sc_ctx_set_onelane_mode", "sc_ctx_set_chip_share",
 ]
 
 
@@ -79,6 +79,7 @@ def load() -> C.CDLL:
         "sc_table_traffic_probe": (i32, [vp, i32, vp, vp, u64, i32, i32, C.POINTER(C.c_int)]),
         "sc_ctx_set_latency_mode": (i32, [vp, i32]),
         "sc_ctx_set_onelane_mode": (i32, [vp, i32]),
+        "sc_ctx_set_chip_share": (i32, [vp, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol

@@ -156,10 +156,17 @@ class ConcurrentShards:
         if len(set(engines)) != len(engines):
             raise ValueError("every shard needs its own engine (library context)")
         self.parties = parties
+        for p in parties:     # every shard's launches share the chip with the other shards' (batch-size policies of the library)
+            for scheme in (p.alice_paillier, p.alice_dgk, p.bob_paillier, p.bob_dgk):
+                if hasattr(scheme.engine, "set_chip_share"):
+                    scheme.engine.set_chip_share(len(parties))
         self._pool = ThreadPoolExecutor(max_workers=len(parties), thread_name_prefix="sc-shard")
 
     def close(self) -> None:
         self._pool.shutdown(wait=True)
+        for p in self.parties:
+            if hasattr(p.alice_paillier.engine, "set_chip_share"):
+                p.alice_paillier.engine.set_chip_share(1)
 
     def run(self, shards: list[tuple[torch.Tensor, torch.Tensor, BatchDraws]], l: int, randomize: bool | str = True) -> list[torch.Tensor]:
         """shards[i] = (x_enc, y_enc, draws) of shard i; returns the per-shard [[x <= y]] arrays."""

@@ -171,6 +171,7 @@ struct sc_ctx {
   std::map<std::pair<int, std::vector<uint32_t>>, int> const_by_value;  // (mod, residue) -> constant id
   int latency_mode = 1;                                     // sc_ctx_set_latency_mode: 0 never, 1 automatic, 2 whenever available
   int onelane_mode = 1;                                     // sc_ctx_set_onelane_mode: 0 never, 1 automatic, 2 whenever available
+  int chip_share = 1;                                       // sc_ctx_set_chip_share: contexts working on this GPU at the same time
   std::map<int, int> onelane_twins;                         // mod -> context of the same modulus in the one-lane configuration
   std::map<int, int> pair_twins;                            // mod -> context of the same modulus in a pair-capable configuration
   std::map<int, uint32_t*> pair_consts;                     // mod -> 4 limb arrays: pair(R^2), pair(B R) for the pair arithmetic
@@ -1318,13 +1319,16 @@ static int pair_twin(sc_ctx* ctx, int mod) {
 // numbers each: 196608 numbers on 256 CUs).  Measured on the MI355X (1024-bit modulus, 1024-bit exponent): 196608 numbers 19.8 ->
 // 16.6 ms, 2.1 M numbers (zero tests) 37.3 -> 33.0 ms, but 98304 numbers 9.5 -> 11.6 ms -- three quarters of a round leaves a
 // quarter of the SIMDs with one wave and nobody to hide its latencies, where the two-lane form still runs 1.5 full rounds.
+// When several contexts work on the GPU at once (concurrent shards: sc_ctx_set_chip_share) a launch owns its share of the chip
+// only, and the idle SIMDs of an under-filled launch are taken by the other contexts' kernels: the threshold counts rounds of
+// that share (two shards of 32768 comparisons: the 98304-number launches run one-lane, +1.5 % on the whole step).
 static int onelane_for(sc_ctx* ctx, int mod, uint64_t count) {
   if (ctx->onelane_mode == 0) return mod;
   {
     const Mod& m = ctx->mods[mod];
     // the residue arrays (and the raw chunks a wide operand is read in) must fit below R = 2^(28 * 37): at most 32 words
     if (m.W == kOneLane.W || m.nbits + 8 > kOneLane.W * kOneLane.G * kOneLane.L || 32 * m.nwords > kOneLane.W * kOneLane.G * kOneLane.L) return mod;
-    if (ctx->onelane_mode == 1 && count < (uint64_t)ctx->num_cu * 4 * 2 * 64 * 3 / 2) return mod;
+    if (ctx->onelane_mode == 1 && count < (uint64_t)ctx->num_cu * 4 * 2 * 64 * 3 / 2 / (uint64_t)ctx->chip_share) return mod;
   }
   auto it = ctx->onelane_twins.find(mod);
   if (it != ctx->onelane_twins.end()) return it->second < 0 ? mod : it->second;
@@ -1333,6 +1337,12 @@ static int onelane_for(sc_ctx* ctx, int mod, uint64_t count) {
   if (create_mod(ctx, n.data(), (int)n.size(), false, &twin, &kOneLane) != SC_OK) twin = -1;
   ctx->onelane_twins[mod] = twin;
   return twin < 0 ? mod : twin;
+}
+
+int sc_ctx_set_chip_share(sc_ctx* ctx, int contexts) {
+  if (!ctx || contexts < 1 || contexts > 64) return SC_ERR_ARG;
+  ctx->chip_share = contexts;
+  return SC_OK;
 }
 
 int sc_ctx_set_onelane_mode(sc_ctx* ctx, int mode) {
