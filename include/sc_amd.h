@@ -83,7 +83,9 @@ int sc_const_create(sc_ctx* ctx, int mod, const uint32_t* v_hptr, int nwords, in
 int sc_fbt_create(sc_ctx* ctx, int mod, const uint32_t* base_hptr, int exp_bits, int window, int* out_fbt);
 /* Use a table another context of the same device built for the same modulus (a window-20 table for h is 6 GB: concurrent
  * shard contexts of one GPU read one copy).  The rows are read-only and reference-counted: they are freed when the last
- * context holding the table is destroyed.  `mod` must be `ctx`'s registration of the modulus the table was built for. */
+ * context holding the table is destroyed.  `mod` must be `ctx`'s registration of the modulus the table was built for.  Call it
+ * while `src_ctx` is idle (its table list is read without a lock); the imported table itself is safe to use from `ctx`'s thread
+ * while `src_ctx` works. */
 int sc_fbt_import(sc_ctx* ctx, int mod, sc_ctx* src_ctx, int src_fbt, int* out_fbt);
 /* Device bytes of a table's rows (reported by bench.py next to the throughput that depends on them). */
 int sc_fbt_bytes(sc_ctx* ctx, int fbt, uint64_t* out_bytes);
@@ -96,6 +98,11 @@ int sc_modmul(sc_ctx* ctx, int mod, const uint32_t* a_dptr, int a_stride_words, 
 /* out[i] = a[i] * c mod n for a registered constant c (ct + int with int in {0,1}: SC/initiator.py:320,
  * 476, 484, 531). */
 int sc_modmul_const(sc_ctx* ctx, int mod, const uint32_t* a_dptr, int cst, uint32_t* out_dptr, uint64_t count);
+/* out[i] = a[i] * (flags[i] ? c1 : c0) mod n for registered constants (-1 = the residue 1), one byte flag per item: the
+ * unrandomized DGK encryption of a bit folded into its randomizer, g^bit * h^r (SC/keyholder.py:213, 231 with :106-108) --
+ * no array of g^bit values is ever materialised. */
+int sc_modmul_const_sel(sc_ctx* ctx, int mod, const uint32_t* a_dptr, int cst0, int cst1, const uint8_t* flags_dptr,
+                        uint32_t* out_dptr, uint64_t count);
 /* out[i] = x[i]^e mod n [* mul_into[i]], e shared: Paillier rho^N mod N^2 (SC/initiator.py:109,
  * SC/keyholder.py:126-128), c^lambda (SC/keyholder.py:195), w^(2^i) (SC/initiator.py:406), w_sum^3 (:480).
  * x may be wider than the modulus (x_words > nwords): it is reduced first (DGK zero test works mod p). */

@@ -12,7 +12,7 @@ SYMBOLS = [
     "sc_ctx_create", "sc_ctx_destroy", "sc_ctx_set_stream", "sc_ctx_synchronize", "sc_last_error", "sc_abi_version",
     "sc_malloc", "sc_free", "sc_memcpy_h2d", "sc_memcpy_d2h",
     "sc_mod_create", "sc_mod_words", "sc_exp_create", "sc_const_create", "sc_fbt_create", "sc_fbt_import", "sc_fbt_bytes",
-    "sc_modmul", "sc_modmul_const", "sc_modexp_shared", "sc_modexp_shared_sq", "sc_mod_supports_sq", "sc_modexp_shared_isone", "sc_modexp_shared_isone_any", "sc_fixedbase_pow", "sc_modexp_var", "sc_modexp_var_scatter",
+    "sc_modmul", "sc_modmul_const", "sc_modmul_const_sel", "sc_modexp_shared", "sc_modexp_shared_sq", "sc_mod_supports_sq", "sc_modexp_shared_isone", "sc_modexp_shared_isone_any", "sc_fixedbase_pow", "sc_modexp_var", "sc_modexp_var_scatter",
     "sc_modinv", "sc_paillier_encrypt_raw", "sc_paillier_encrypt_raw_neg", "sc_paillier_l_mul", "sc_crt_combine", "sc_plain_alice", "sc_plain_bob", "sc_dgk_step4",
     "sc_peak_probe", "sc_mac_counter", "sc_table_traffic_probe", "sc_ctx_set_latency_mode", "sc_ctx_set_onelane_mode", "sc_ctx_set_chip_share",
 ]
@@ -58,6 +58,7 @@ def load() -> C.CDLL:
         "sc_fbt_bytes": (i32, [vp, i32, C.POINTER(C.c_uint64)]),
         "sc_modmul": (i32, [vp, i32, vp, i32, vp, i32, vp, u64]),
         "sc_modmul_const": (i32, [vp, i32, vp, i32, vp, u64]),
+        "sc_modmul_const_sel": (i32, [vp, i32, vp, i32, i32, vp, vp, u64]),
         "sc_modexp_shared": (i32, [vp, i32, i32, vp, i32, vp, vp, u64]),
         "sc_modexp_shared_sq": (i32, [vp, i32, i32, i32, vp, i32, vp, vp, u64]),
         "sc_mod_supports_sq": (i32, [vp, i32]),

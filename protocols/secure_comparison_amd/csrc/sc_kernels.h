@@ -68,6 +68,9 @@ __global__ void __launch_bounds__(64, (G == 1 && L == 37) ? 2 : (L == 27 ? SC_L2
       if (opc == OP_MUL || opc == OP_LOADT) {
         if (akind == AK_CONST) {
           a_ptr = s_c + op.w1 * SP;
+        } else if (akind == AK_CONSTSEL) {   // one of two LDS constants, chosen per item by a byte flag (control flow stays uniform)
+          const uint8_t f = ((const uint8_t*)args.ext[op.w1 & 0xf].ptr)[idx];
+          a_ptr = s_c + ((f ? (op.w2 >> 8) : op.w2) & 0xff) * SP;
         } else if (akind == AK_TBL) {
           src_limbs = my_tbl + (uint64_t)op.w1 * S * TS;
           src_ts = TS;
@@ -143,7 +146,7 @@ __global__ void __launch_bounds__(64, (G == 1 && L == 37) ? 2 : (L == 27 ? SC_L2
           break;
         }
         case OP_LOADT: {
-          if (akind == AK_CONST || src_is_one) {
+          if (akind == AK_CONST || akind == AK_CONSTSEL || src_is_one) {
             const uint32_t* c = src_is_one ? s_c + 1 * SP : a_ptr;
 #pragma unroll
             for (int l = 0; l < L; l++) acc[l] = c[gp.j * L + l];

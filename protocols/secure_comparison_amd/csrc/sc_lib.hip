@@ -741,6 +741,27 @@ int sc_modmul_const(sc_ctx* ctx, int mod, const uint32_t* a, int cst, uint32_t* 
   return run_vm(ctx, mod, it->second, ex, 2, count);
 }
 
+int sc_modmul_const_sel(sc_ctx* ctx, int mod, const uint32_t* a, int cst0, int cst1, const uint8_t* flags, uint32_t* out, uint64_t count) {
+  if (ctx && count == 0) return SC_OK;
+  if (!valid_mod(ctx, mod) || !a || !flags || !out) return fail(ctx, SC_ERR_ARG, "sc_modmul_const_sel: bad argument");
+  for (int c : {cst0, cst1})
+    if (c != -1 && (c < 0 || c >= (int)ctx->consts.size() || ctx->consts[c].mod != mod)) return fail(ctx, SC_ERR_ARG, "sc_modmul_const_sel: bad constant");
+  const Mod& m = ctx->mods[mod];
+  std::string key = "mmsel:" + std::to_string(mod) + ":" + std::to_string(cst0) + ":" + std::to_string(cst1);
+  auto it = ctx->progs.find(key);
+  if (it == ctx->progs.end()) {
+    Builder bd;
+    const int l0 = cst0 < 0 ? 1 : bd.use_const(cst0), l1 = cst1 < 0 ? 1 : bd.use_const(cst1);   // LDS constant 1 = R mod n = the residue 1
+    bd.loadw(0);
+    bd.emit(OP_MUL, AK_CONSTSEL, 0, 2, (uint32_t)l0 | ((uint32_t)l1 << 8)); bd.muls++;           // a * (c R) / R = a c
+    bd.storew(1); bd.end();
+    Prog p; int rc = finalize_prog(ctx, m, bd, &p); if (rc) return rc;
+    it = ctx->progs.emplace(key, p).first;
+  }
+  VmExt ex[3] = {mk_ext(a, m.nwords, m.nwords), mk_ext(out, m.nwords, m.nwords), mk_ext(flags, 0, 0)};
+  return run_vm(ctx, mod, it->second, ex, 3, count);
+}
+
 static int onelane_for(sc_ctx* ctx, int mod, uint64_t count);
 
 static int modexp_shared_impl(sc_ctx* ctx, int mod, int exp, const uint32_t* x, int x_words, const uint32_t* mul_into,

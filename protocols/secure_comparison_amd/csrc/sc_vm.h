@@ -52,6 +52,7 @@ enum VmAKind : uint32_t {
   AK_FBT = 5,     // w1 = ext | bitpos<<4 | width<<24 ; w2 = window index ; row = fbt[(win << width) + digit]
   AK_EXTW = 6,    // w1 = ext, w2 = off : plain words operand (staged through LDS)
   AK_EXTL = 7,    // w1 = ext, w2 = off : limb-form operand in an ext array (ext stride: S, or 0 = broadcast)
+  AK_CONSTSEL = 8,  // w1 = ext (one byte per item), w2 = LDS constant index for byte 0 | index for byte != 0 << 8
 };
 
 struct VmOp {

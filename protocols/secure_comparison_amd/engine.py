@@ -220,6 +220,20 @@ class Engine:
         self._check(self.lib.sc_modmul_const(self.ctx, mod.id, self._ptr(a), self.constant(mod, c), self._ptr(out), count))
         return out
 
+    def modmul_const_sel(self, mod: Modulus, a: torch.Tensor, c0: int | None, c1: int | None, flags: torch.Tensor,
+                         out: torch.Tensor | None = None) -> torch.Tensor:
+        """a[i] * (flags[i] ? c1 : c0) mod n; None = the residue 1; flags: uint8 [count]."""
+        count = self._items(a)
+        self._arr(a, "a", count, mod.nwords)
+        self._arr(flags, "flags", dtype=torch.uint8)
+        if flags.numel() != count:
+            raise ValueError(f"flags: {flags.numel()} items, expected {count}")
+        out = self._out(out, count, mod.nwords)
+        self._sync_stream()
+        k0, k1 = (-1 if c0 is None else self.constant(mod, c0)), (-1 if c1 is None else self.constant(mod, c1))
+        self._check(self.lib.sc_modmul_const_sel(self.ctx, mod.id, self._ptr(a), k0, k1, self._ptr(flags), self._ptr(out), count))
+        return out
+
     def modexp_shared(self, mod: Modulus, x: torch.Tensor, e: int, mul_into: torch.Tensor | None = None,
                       out: torch.Tensor | None = None) -> torch.Tensor:
         """x^e mod n for an exponent shared by the batch (key-derived: N, lambda, p - 1, v_p, ...: each distinct exponent is

@@ -193,9 +193,10 @@ class KeyHolder:
         count = plain.beta.shape[0]
         shifts = torch.arange(l, device=plain.beta.device, dtype=torch.int64).reshape(l, 1)
         bits = torch.cat([plain.d.reshape(1, count), (plain.beta.reshape(1, count) >> shifts) & 1], dim=0)  # [l+1][B]
-        enc = scheme_dgk.encrypt_bits_batch(bits.reshape(-1))
         if randomizer_exponents is not None:
-            enc = scheme_dgk.randomize_batch(enc, randomizer_exponents.reshape((l + 1) * count, -1))
+            enc = scheme_dgk.encrypt_bits_randomized_batch(bits.reshape(-1), randomizer_exponents.reshape((l + 1) * count, -1))
+        else:
+            enc = scheme_dgk.encrypt_bits_batch(bits.reshape(-1))
         enc = enc.reshape(l + 1, count, -1)
         return enc[0].contiguous(), enc[1:].contiguous()
 

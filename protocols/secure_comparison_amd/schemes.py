@@ -583,6 +583,14 @@ class DGK(_Scheme):
             self._bit_words = e.upload([1, self.public_key.g], self.mod_n.nwords)
         return self._bit_words[(bits != 0).reshape(-1).to(torch.int64)]
 
+    def encrypt_bits_randomized_batch(self, bits: torch.Tensor, r: torch.Tensor) -> torch.Tensor:
+        """g^b * h^r for bits b [count] and exponent words r [count][ewords]: `unsafe_encrypt(bit)` and `.randomize()` of
+        SC/keyholder.py:213, 231 and :106-108 in one go -- the randomizer h^r times the constant g or 1, chosen per item by a
+        byte flag inside the launch (no array of g^b is materialised)."""
+        hr = self.randomize_batch(None, r)
+        flags = (bits.reshape(-1) != 0).to(torch.uint8)
+        return self.engine.modmul_const_sel(self.mod_n, hr, None, self.public_key.g, flags, out=hr)
+
     def randomize_batch(self, c: torch.Tensor | None, r: torch.Tensor) -> torch.Tensor:
         """c * h^r mod n for exponent words r [count][ewords] (SC/keyholder.py:106-108; SC/initiator.py:153-154).
         The key holder (who knows p, q, v_p, v_q) goes through CRT: h has order v_p modulo p, so h^r mod p =

@@ -70,6 +70,10 @@ class OracleEngine:
     def modmul_const(self, mod, a, c, out=None):
         return self.upload([x * c % mod.n for x in self._ints(a)], mod.nwords)
 
+    def modmul_const_sel(self, mod, a, c0, c1, flags, out=None):
+        k0, k1 = (1 if c0 is None else c0), (1 if c1 is None else c1)
+        return self.upload([x * (k1 if f else k0) % mod.n for x, f in zip(self._ints(a), flags.tolist())], mod.nwords)
+
     def modexp_shared(self, mod, x, e, mul_into=None, out=None):
         r = [pow(v, e, mod.n) for v in self._ints(x)]
         if mul_into is not None:

@@ -302,3 +302,21 @@ def test_fused_any_zero_equals_or_of_zero_tests(engine, keys, mode):
         engine.set_onelane_mode(1)
     expect = [int(any(ms[i][b] == 0 for i in range(planes))) for b in range(B)]
     assert got == expect == (flags != 0).any(dim=0).to(torch.int64).tolist() and sum(expect) == 4
+
+
+def test_selected_constant_product(engine, keys):
+    """sc_modmul_const_sel: a[i] * (flag ? c1 : c0), the residue 1 as default constant, in place, ragged count."""
+    dgk = oracle_dgk(keys, "dgk_2048_l32")
+    rng = random.Random(9)
+    mod = engine.modulus(dgk.n)
+    count = 201
+    xs = [0, 1, dgk.n - 1] + [rng.randrange(dgk.n) for _ in range(count - 3)]
+    fl = [rng.randrange(2) * rng.choice([1, 1, 255]) for _ in range(count)]
+    t = engine.upload(xs, mod.nwords)
+    flags = torch.tensor(fl, dtype=torch.uint8, device=engine.device)
+    assert engine.download(engine.modmul_const_sel(mod, t, None, dgk.g, flags)) == [x * (dgk.g if f else 1) % dgk.n for x, f in zip(xs, fl)]
+    assert engine.download(engine.modmul_const_sel(mod, t, dgk.h, dgk.g, flags, out=t)) == [x * (dgk.g if f else dgk.h) % dgk.n for x, f in zip(xs, fl)]
+    with pytest.raises(ValueError):
+        engine.modmul_const_sel(mod, t, None, dgk.g, flags[:-1])
+    with pytest.raises(ValueError):
+        engine.modmul_const_sel(mod, t, None, dgk.g, flags.to(torch.int32))
