@@ -43,6 +43,7 @@ def protocol_round(engine, rng):
     rbits = int(2.5 * v_bits)
     use_crt = rng.random() < 0.7
     engine.set_latency_mode(rng.choice([0, 1, 2]))
+    engine.set_onelane_mode(rng.choice([0, 1, 2]))
     bob_p = Paillier(sk.n, sk.p, sk.q, engine=engine, use_crt=use_crt, use_pairs=rng.random() < 0.8)
     bob_d = DGK(dgk.n, dgk.g, dgk.h, dgk.u, dgk.t, dgk.p, dgk.q, dgk.v_p, dgk.v_q, engine=engine, randomizer_bits=rbits,
                 fixed_base_window=rng.choice([1, 3, 8, 11]), use_crt=rng.random() < 0.7)
@@ -73,8 +74,11 @@ def run_protocol_fuzz(engine, budget, seed):
         while time.time() < t_end:
             protocol_round(engine, rng)
             rounds += 1
+            if rounds % 10 == 0:
+                print(rounds, "protocol rounds ok", flush=True)
     finally:
         engine.set_latency_mode(0)
+        engine.set_onelane_mode(1)
     return rounds
 
 
