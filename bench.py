@@ -156,6 +156,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=0)
     ap.add_argument("--no-extras", action="store_true", help="skip the informational legs (window sensitivity, online phase, PCIe-inclusive)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (exercises the RCCL path)")
+    ap.add_argument("--c-abi-gather", action="store_true", help="after the timed region, repeat the reassembly through the C ABI's own RCCL communicator "
+                    "(sc_comm_init / sc_allgather) and report whether it equals torch.distributed's gather")
     return ap.parse_args(argv)
 
 
@@ -302,6 +304,24 @@ def main() -> None:
     value = world * B * args.steps / elapsed
     if not all_correct(res):
         raise SystemExit("bench.py: decrypted results of the timed steps differ from x <= y")
+    # outside the timed region: the same reassembly through the C ABI's own RCCL communicator (sc_comm_init / sc_allgather,
+    # what a host without torch would call), compared with torch.distributed's gather.  Opt-in (--c-abi-gather: a second
+    # communicator's rendezvous is not something the scaling run should depend on); reported, never fatal.
+    c_abi_gather = None
+    if dist is not None and args.c_abi_gather:
+        try:
+            from protocols.secure_comparison_amd.distributed import comm_init_from_torch
+
+            comm_init_from_torch(eng)
+            mine = res[rank * B:(rank + 1) * B].contiguous() if world > 1 else res.contiguous()
+            again = eng.allgather(mine)
+            torch.cuda.synchronize()
+            ok_t = torch.tensor([int(torch.equal(again, res))], dtype=torch.int64, device=eng.device)
+            dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+            c_abi_gather = {"equal_to_torch_gather": bool(ok_t.item()), "ranks": world}
+            eng.comm_destroy()
+        except Exception as exc:  # pragma: no cover
+            c_abi_gather = {"error": str(exc)[:200]}
 
     out = None
     if rank == 0:
@@ -350,7 +370,7 @@ def main() -> None:
             "metric": "secure comparisons/sec (l=%d, %d-bit keys)" % (l, args.pbits), "value": value, "unit": "comparisons/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 (29-bit limbs held in u32, 32x32+64->64 multiply-accumulate)",
-            "data": "synthetic", "rccl_ranks": rccl_ranks, "rank_devices": devices,
+            "data": "synthetic", "rccl_ranks": rccl_ranks, "rank_devices": devices, "c_abi_gather": c_abi_gather,
             "config": {"workload": "batch %d comparisons per GPU, l=%d, %d-bit Paillier + %d-bit DGK (%s)" % (B, l, args.pbits, dbits, cfg_name),
                        "batch_per_gpu": B, "l": l, "paillier_bits": args.pbits, "dgk_bits": dbits, "dgk_key": dname, "dgk_randomizer_bits": args.rbits,
                        "fixed_base_window": args.fb_window, "keyholder_crt": use_crt, "shuffle_4i": not args.no_shuffle,

@@ -193,6 +193,22 @@ int sc_dgk_step4(sc_ctx* ctx, int mod, int cst_g, int cst_ginv, int l, const uin
                  const uint64_t* alpha_dptr, const uint64_t* alpha_tilde_dptr, const uint64_t* rsmall_dptr,
                  const uint64_t* delta_a_dptr, uint32_t* c_out_dptr, uint64_t count);
 
+/* ---- multi-GPU ---------------------------------------------------------------------- */
+/* The comparisons of a batch are independent: every rank (one process and one context per GPU) runs all steps on its own block
+ * with no traffic during compute; the only exchange is the reassembly of the ranks' result blocks -- [[x <= y]], or the per-bit
+ * vectors in the blocked layout [rank][l+1][B/ranks][words] -- by ONE all-gather (RCCL over xGMI) on the context's stream.  The
+ * reference has no counterpart (its only concurrency is session_id namespacing, SC/initiator.py:86-87).  RCCL is loaded on first
+ * use (dlopen), so single-GPU users never need it.
+ *   sc_comm_unique_id: rank 0 creates the 128-byte rendezvous id (SC_COMM_ID_BYTES); the caller ships it to the other ranks.
+ *   sc_comm_init:      every rank joins with the same id (collective call).
+ *   sc_allgather:      recv[r * words_per_rank ..] = rank r's send[0 .. words_per_rank) for every r; asynchronous on the stream.
+ *   sc_comm_destroy:   also done by sc_ctx_destroy. */
+#define SC_COMM_ID_BYTES 128
+int sc_comm_unique_id(sc_ctx* ctx, void* id_hptr);
+int sc_comm_init(sc_ctx* ctx, const void* id_hptr, int rank, int nranks);
+int sc_allgather(sc_ctx* ctx, const uint32_t* send_dptr, uint32_t* recv_dptr, uint64_t words_per_rank);
+int sc_comm_destroy(sc_ctx* ctx);
+
 /* ---- measurement -------------------------------------------------------------------------------- */
 /* Runs an on-device v_mad_u64_u32 issue-rate probe; returns lane-MACs per second (the VALU-integer peak
  * used as the roofline denominator).  Synchronous. */

@@ -14,7 +14,7 @@ SYMBOLS = [
     "sc_mod_create", "sc_mod_words", "sc_exp_create", "sc_const_create", "sc_fbt_create", "sc_fbt_import", "sc_fbt_bytes",
     "sc_modmul", "sc_modmul_const", "sc_modmul_const_sel", "sc_modexp_shared", "sc_modexp_shared_sq", "sc_mod_supports_sq", "sc_modexp_shared_isone", "sc_modexp_shared_isone_any", "sc_fixedbase_pow", "sc_modexp_var", "sc_modexp_var_scatter",
     "sc_modinv", "sc_paillier_encrypt_raw", "sc_paillier_encrypt_raw_neg", "sc_paillier_l_mul", "sc_crt_combine", "sc_plain_alice", "sc_plain_bob", "sc_dgk_step4",
-    "sc_peak_probe", "sc_mac_counter", "sc_table_traffic_probe", "sc_ctx_set_latency_mode", "sc_ctx_set_onelane_mode", "sc_ctx_set_chip_share",
+    "sc_peak_probe", "sc_mac_counter", "sc_table_traffic_probe", "sc_ctx_set_latency_mode", "sc_ctx_set_onelane_mode", "sc_ctx_set_chip_share", "sc_comm_unique_id", "sc_comm_init", "sc_allgather", "sc_comm_destroy",
 ]
 
 
@@ -81,6 +81,10 @@ def load() -> C.CDLL:
         "sc_ctx_set_latency_mode": (i32, [vp, i32]),
         "sc_ctx_set_onelane_mode": (i32, [vp, i32]),
         "sc_ctx_set_chip_share": (i32, [vp, i32]),
+        "sc_comm_unique_id": (i32, [vp, vp]),
+        "sc_comm_init": (i32, [vp, vp, i32, i32]),
+        "sc_allgather": (i32, [vp, vp, vp, u64]),
+        "sc_comm_destroy": (i32, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol

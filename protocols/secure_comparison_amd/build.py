@@ -27,7 +27,7 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
     # -pragma-unroll-threshold: the L = 27 limb-step loops (1458 multiply-adds per block) must be fully unrolled, otherwise
     # the column registers are indexed dynamically and land in scratch memory (50x slower)
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-pragma-unroll-threshold=1000000",
-           SRC, "-o", OUT]
+           SRC, "-o", OUT, "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     proc = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)

@@ -1,6 +1,7 @@
 // libsc_amd.so -- host side of the C ABI declared in include/sc_amd.h.
 // Builds the micro-programs (sc_vm.h) for each batched operation and launches the gfx950 kernels.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdarg>
@@ -172,6 +173,8 @@ struct sc_ctx {
   int latency_mode = 1;                                     // sc_ctx_set_latency_mode: 0 never, 1 automatic, 2 whenever available
   int onelane_mode = 1;                                     // sc_ctx_set_onelane_mode: 0 never, 1 automatic, 2 whenever available
   int chip_share = 1;                                       // sc_ctx_set_chip_share: contexts working on this GPU at the same time
+  void* comm = nullptr;                                     // RCCL communicator of this rank (sc_comm_init), one context per GPU
+  int comm_rank = 0, comm_nranks = 0;
   std::map<int, int> onelane_twins;                         // mod -> context of the same modulus in the one-lane configuration
   std::map<int, int> pair_twins;                            // mod -> context of the same modulus in a pair-capable configuration
   std::map<int, uint32_t*> pair_consts;                     // mod -> 4 limb arrays: pair(R^2), pair(B R) for the pair arithmetic
@@ -547,6 +550,7 @@ void sc_ctx_destroy(sc_ctx* ctx) {
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   for (auto& kv : ctx->tmp) if (kv.second.first) (void)hipFree(kv.second.first);
   if (ctx->switch_event) (void)hipEventDestroy(ctx->switch_event);
+  if (ctx->comm) (void)sc_comm_destroy(ctx);
   delete ctx;
 }
 
@@ -1471,6 +1475,100 @@ int sc_modexp_shared_sq(sc_ctx* ctx, int mod_m, int mod_m2, int exp, const uint3
   }
   VmExt ex4[4] = {mk_ext(d_w, wm, wm), mk_ext(d_w1, wm, wm), mk_ext(mul_into, m2.nwords, m2.nwords), mk_ext(out, m2.nwords, m2.nwords)};
   return run_vm(ctx, mod_m2, it2->second, ex4, 4, count);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Multi-GPU: comparisons are independent, so the only exchange is the reassembly of per-rank result blocks -- one
+// RCCL all-gather over xGMI on the context's stream.  RCCL is bound at run time (dlopen): a single-GPU user never loads it, and
+// a process that already runs torch.distributed gets the very library instance torch loaded.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct RcclId { char internal[128]; };
+struct RcclApi {
+  void* handle = nullptr;
+  int (*GetUniqueId)(RcclId*) = nullptr;
+  int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi* rccl_api(std::string* why) {
+  static RcclApi api;
+  static bool tried = false;
+  static std::string err;
+  if (!tried) {
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+      api.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (api.handle) break;
+    }
+    if (!api.handle) {
+      err = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "not found");
+    } else {
+      api.GetUniqueId = (int (*)(RcclId*))dlsym(api.handle, "ncclGetUniqueId");
+      api.CommInitRank = (int (*)(void**, int, RcclId, int))dlsym(api.handle, "ncclCommInitRank");
+      api.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(api.handle, "ncclAllGather");
+      api.CommDestroy = (int (*)(void*))dlsym(api.handle, "ncclCommDestroy");
+      api.GetErrorString = (const char* (*)(int))dlsym(api.handle, "ncclGetErrorString");
+      if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy) { err = "librccl lacks an expected symbol"; api.handle = nullptr; }
+    }
+  }
+  if (!api.handle) { if (why) *why = err; return nullptr; }
+  return &api;
+}
+int rccl_fail(sc_ctx* ctx, RcclApi* api, const char* what, int code) {
+  return fail(ctx, SC_ERR_HIP, "%s: %s", what, api->GetErrorString ? api->GetErrorString(code) : "RCCL error");
+}
+}  // namespace
+
+int sc_comm_unique_id(sc_ctx* ctx, void* id_hptr) {
+  if (!ctx || !id_hptr) return fail(ctx, SC_ERR_ARG, "sc_comm_unique_id: bad argument");
+  std::string why;
+  RcclApi* api = rccl_api(&why);
+  if (!api) return fail(ctx, SC_ERR_UNSUPPORTED, "%s", why.c_str());
+  RcclId id;
+  const int rc = api->GetUniqueId(&id);
+  if (rc) return rccl_fail(ctx, api, "ncclGetUniqueId", rc);
+  memcpy(id_hptr, id.internal, sizeof id.internal);
+  return SC_OK;
+}
+
+int sc_comm_init(sc_ctx* ctx, const void* id_hptr, int rank, int nranks) {
+  if (!ctx || !id_hptr || nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, SC_ERR_ARG, "sc_comm_init: bad argument");
+  if (ctx->comm) return fail(ctx, SC_ERR_ARG, "sc_comm_init: the context already has a communicator");
+  std::string why;
+  RcclApi* api = rccl_api(&why);
+  if (!api) return fail(ctx, SC_ERR_UNSUPPORTED, "%s", why.c_str());
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  RcclId id;
+  memcpy(id.internal, id_hptr, sizeof id.internal);
+  void* comm = nullptr;
+  const int rc = api->CommInitRank(&comm, nranks, id, rank);
+  if (rc) return rccl_fail(ctx, api, "ncclCommInitRank", rc);
+  ctx->comm = comm; ctx->comm_rank = rank; ctx->comm_nranks = nranks;
+  return SC_OK;
+}
+
+int sc_allgather(sc_ctx* ctx, const uint32_t* send, uint32_t* recv, uint64_t words_per_rank) {
+  if (!ctx || !ctx->comm) return fail(ctx, SC_ERR_ARG, "sc_allgather: no communicator (sc_comm_init)");
+  if (words_per_rank == 0) return SC_OK;
+  if (!send || !recv) return fail(ctx, SC_ERR_ARG, "sc_allgather: bad argument");
+  RcclApi* api = rccl_api(nullptr);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int rc = api->AllGather(send, recv, (size_t)words_per_rank, 3 /* ncclUint32 */, ctx->comm, ctx->stream);
+  if (rc) return rccl_fail(ctx, api, "ncclAllGather", rc);
+  return SC_OK;
+}
+
+int sc_comm_destroy(sc_ctx* ctx) {
+  if (!ctx) return SC_ERR_ARG;
+  if (!ctx->comm) return SC_OK;
+  RcclApi* api = rccl_api(nullptr);
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  const int rc = api ? api->CommDestroy(ctx->comm) : 0;
+  ctx->comm = nullptr; ctx->comm_nranks = 0;
+  return rc ? rccl_fail(ctx, api, "ncclCommDestroy", rc) : SC_OK;
 }
 
 int sc_peak_probe(sc_ctx* ctx, double* out_mac_per_s) {

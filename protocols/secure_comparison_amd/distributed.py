@@ -48,3 +48,13 @@ def all_gather_planes(local: torch.Tensor, group=None) -> torch.Tensor:
     # (the collective wants the ranks concatenated along the first axis; the blocked layout is that very memory)
     dist.all_gather_into_tensor(out.view((world * local.shape[0],) + tuple(local.shape[1:])), local.contiguous(), group=group)
     return out
+
+
+def comm_init_from_torch(engine, group=None) -> None:
+    """Give `engine` (this rank's library context) an RCCL communicator of its own through the C ABI (sc_comm_init), using an
+    existing torch.distributed group only to ship the 128-byte rendezvous id from rank 0 to the others.  Afterwards
+    `engine.allgather(local)` reassembles result blocks without torch (what a non-torch host would call)."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    box = [engine.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    engine.comm_init(box[0], rank, world)

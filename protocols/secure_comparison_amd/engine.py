@@ -425,6 +425,36 @@ class Engine:
                                           self._ptr(out), count))
         return out
 
+    # ------------------------------------------------------------------ multi-GPU through the C ABI (one engine per GPU / process)
+    def comm_unique_id(self) -> bytes:
+        """Rendezvous id for sc_comm_init (rank 0 creates it and ships it to the other ranks)."""
+        buf = (C.c_char * 128)()
+        self._check(self.lib.sc_comm_unique_id(self.ctx, C.cast(buf, C.c_void_p)))
+        return bytes(buf)
+
+    def comm_init(self, comm_id: bytes, rank: int, nranks: int) -> None:
+        if len(comm_id) != 128:
+            raise ValueError("the rendezvous id has 128 bytes")
+        buf = (C.c_char * 128).from_buffer_copy(comm_id)
+        self._check(self.lib.sc_comm_init(self.ctx, C.cast(buf, C.c_void_p), int(rank), int(nranks)))
+        self._comm_nranks = int(nranks)
+
+    def allgather(self, local: torch.Tensor) -> torch.Tensor:
+        """All ranks' `local` arrays (same shape, int32 words) stacked in rank order along the first axis: one RCCL all-gather on
+        the engine's stream (sc_allgather)."""
+        n = getattr(self, "_comm_nranks", 0)
+        if n < 1:
+            raise ScError("no communicator: call comm_init first")
+        self._arr(local, "local")
+        out = torch.empty((n * local.shape[0],) + tuple(local.shape[1:]), dtype=torch.int32, device=self.device)
+        self._sync_stream()
+        self._check(self.lib.sc_allgather(self.ctx, self._ptr(local), self._ptr(out), local.numel()))
+        return out
+
+    def comm_destroy(self) -> None:
+        self._check(self.lib.sc_comm_destroy(self.ctx))
+        self._comm_nranks = 0
+
     def peak_probe(self) -> float:
         v = C.c_double()
         self._sync_stream()

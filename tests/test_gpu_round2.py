@@ -166,11 +166,12 @@ def test_bench_rank_handling_on_one_gpu():
     """`bench.py --gpus 1 --force-dist` goes through RCCL with one rank and says so; `--gpus 2` on a one-GPU box fails."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     bench = os.path.join(ROOT, "bench.py")
-    cp = subprocess.run([sys.executable, bench, "--gpus", "1", "--force-dist", "--batch", "512", "--l", "16", "--dgk", "dgk_2048_l16", "--fb-window", "8",
+    cp = subprocess.run([sys.executable, bench, "--gpus", "1", "--force-dist", "--c-abi-gather", "--batch", "512", "--l", "16", "--dgk", "dgk_2048_l16", "--fb-window", "8",
                          "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=600)
     assert cp.returncode == 0, cp.stderr[-2000:]
     line = json.loads(cp.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and line["rank_devices"] == [0] and line["value"] > 0
+    assert line["c_abi_gather"] == {"equal_to_torch_gather": True, "ranks": 1}
     assert 0 < line["roofline"]["frac"] < 1 and line["config"]["fixed_base_table_bytes"] > 0
     if torch.cuda.device_count() < 2:
         cp = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
@@ -320,3 +321,24 @@ def test_selected_constant_product(engine, keys):
         engine.modmul_const_sel(mod, t, None, dgk.g, flags[:-1])
     with pytest.raises(ValueError):
         engine.modmul_const_sel(mod, t, None, dgk.g, flags.to(torch.int32))
+
+
+def test_c_abi_allgather_single_rank(engine):
+    """sc_comm_unique_id / sc_comm_init / sc_allgather / sc_comm_destroy through RCCL with one rank (the boxes of this build have
+    one GPU): the gather is the identity, asynchronous on the engine's stream, and a second init is refused."""
+    from protocols.secure_comparison_amd.engine import Engine
+
+    eng = Engine()
+    cid = eng.comm_unique_id()
+    assert len(cid) == 128 and any(cid)
+    with pytest.raises(Exception):
+        eng.allgather(torch.zeros((2, 4), dtype=torch.int32, device=eng.device))      # no communicator yet
+    eng.comm_init(cid, 0, 1)
+    with pytest.raises(ValueError):
+        eng.comm_init(cid, 0, 1)
+    x = torch.arange(3 * 5 * 128, dtype=torch.int32, device=eng.device).reshape(3, 5, 128)
+    got = eng.allgather(x)
+    torch.cuda.synchronize()
+    assert got.shape == (3, 5, 128) and torch.equal(got, x)
+    eng.comm_destroy()
+    eng.close()
