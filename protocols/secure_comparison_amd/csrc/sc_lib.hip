@@ -1492,29 +1492,30 @@ struct RcclApi {
   int (*CommDestroy)(void*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
-RcclApi* rccl_api(std::string* why) {
-  static RcclApi api;
-  static bool tried = false;
-  static std::string err;
-  if (!tried) {
-    tried = true;
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-      api.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-      if (api.handle) break;
-    }
-    if (!api.handle) {
-      err = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "not found");
-    } else {
-      api.GetUniqueId = (int (*)(RcclId*))dlsym(api.handle, "ncclGetUniqueId");
-      api.CommInitRank = (int (*)(void**, int, RcclId, int))dlsym(api.handle, "ncclCommInitRank");
-      api.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(api.handle, "ncclAllGather");
-      api.CommDestroy = (int (*)(void*))dlsym(api.handle, "ncclCommDestroy");
-      api.GetErrorString = (const char* (*)(int))dlsym(api.handle, "ncclGetErrorString");
-      if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy) { err = "librccl lacks an expected symbol"; api.handle = nullptr; }
-    }
+struct RcclLoad { RcclApi api; std::string err; };
+RcclLoad rccl_load() {
+  RcclLoad r;
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+    r.api.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (r.api.handle) break;
   }
-  if (!api.handle) { if (why) *why = err; return nullptr; }
-  return &api;
+  if (!r.api.handle) {
+    const char* e = dlerror();
+    r.err = std::string("cannot load librccl: ") + (e ? e : "not found");
+    return r;
+  }
+  r.api.GetUniqueId = (int (*)(RcclId*))dlsym(r.api.handle, "ncclGetUniqueId");
+  r.api.CommInitRank = (int (*)(void**, int, RcclId, int))dlsym(r.api.handle, "ncclCommInitRank");
+  r.api.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(r.api.handle, "ncclAllGather");
+  r.api.CommDestroy = (int (*)(void*))dlsym(r.api.handle, "ncclCommDestroy");
+  r.api.GetErrorString = (const char* (*)(int))dlsym(r.api.handle, "ncclGetErrorString");
+  if (!r.api.GetUniqueId || !r.api.CommInitRank || !r.api.AllGather || !r.api.CommDestroy) { r.err = "librccl lacks an expected symbol"; r.api.handle = nullptr; }
+  return r;
+}
+RcclApi* rccl_api(std::string* why) {
+  static RcclLoad loaded = rccl_load();   // once per process; initialisation of a local static is thread-safe
+  if (!loaded.api.handle) { if (why) *why = loaded.err; return nullptr; }
+  return &loaded.api;
 }
 int rccl_fail(sc_ctx* ctx, RcclApi* api, const char* what, int code) {
   return fail(ctx, SC_ERR_HIP, "%s: %s", what, api->GetErrorString ? api->GetErrorString(code) : "RCCL error");
