@@ -1493,8 +1493,8 @@ struct RcclApi {
   const char* (*GetErrorString)(int) = nullptr;
 };
 struct RcclLoad { RcclApi api; std::string err; };
-RcclLoad rccl_load() {
-  RcclLoad r;
+void rccl_load(RcclLoad* out) {
+  RcclLoad& r = *out;
   for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
     r.api.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     if (r.api.handle) break;
@@ -1502,7 +1502,7 @@ RcclLoad rccl_load() {
   if (!r.api.handle) {
     const char* e = dlerror();
     r.err = std::string("cannot load librccl: ") + (e ? e : "not found");
-    return r;
+    return;
   }
   r.api.GetUniqueId = (int (*)(RcclId*))dlsym(r.api.handle, "ncclGetUniqueId");
   r.api.CommInitRank = (int (*)(void**, int, RcclId, int))dlsym(r.api.handle, "ncclCommInitRank");
@@ -1510,10 +1510,9 @@ RcclLoad rccl_load() {
   r.api.CommDestroy = (int (*)(void*))dlsym(r.api.handle, "ncclCommDestroy");
   r.api.GetErrorString = (const char* (*)(int))dlsym(r.api.handle, "ncclGetErrorString");
   if (!r.api.GetUniqueId || !r.api.CommInitRank || !r.api.AllGather || !r.api.CommDestroy) { r.err = "librccl lacks an expected symbol"; r.api.handle = nullptr; }
-  return r;
 }
 RcclApi* rccl_api(std::string* why) {
-  static RcclLoad loaded = rccl_load();   // once per process; initialisation of a local static is thread-safe
+  static RcclLoad loaded = [] { RcclLoad r; rccl_load(&r); return r; }();   // once per process; initialisation of a local static is thread-safe
   if (!loaded.api.handle) { if (why) *why = loaded.err; return nullptr; }
   return &loaded.api;
 }
