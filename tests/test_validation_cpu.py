@@ -196,3 +196,23 @@ def test_scalar_multiplication_registers_nothing(world):
     finally:
         eng.modexp_shared = orig
     assert not calls
+
+
+def test_zero_copy_row_joins():
+    """_views.cat_rows: a view when the parts are consecutive blocks of one buffer (what the batch steps hand around), a copy
+    otherwise -- never a wrong answer."""
+    from protocols.secure_comparison_amd._views import cat_rows
+
+    a = torch.arange(5 * 3 * 4, dtype=torch.int32).reshape(5, 3, 4)
+    v = cat_rows([a[0:1], a[1:]])
+    assert v.data_ptr() == a.data_ptr() and torch.equal(v, a)
+    v = cat_rows([a[1:2], a[2:4]])
+    assert v.data_ptr() == a[1:].data_ptr() and torch.equal(v, a[1:4])
+    for parts in ([a[0:1], a[2:]], [a[1:], a[0:1]], [a[:2], a[:2]], [a[:, :2].contiguous()[:1], a[:, :2].contiguous()[1:]][::-1],
+                  [a[::2], a[1::2]]):
+        w = cat_rows(parts)
+        assert torch.equal(w, torch.cat(list(parts), dim=0))
+    b = torch.arange(12, dtype=torch.int32).reshape(6, 2)
+    x = cat_rows([b[:2], b[2:4], b[4:]])
+    assert x.data_ptr() == b.data_ptr() and torch.equal(x, b)
+    assert cat_rows([b[:3], b[3:].to(torch.int64)]).dtype == torch.int64      # mixed dtypes: plain torch.cat semantics
