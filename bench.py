@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 KEYS = os.path.join(ROOT, "tests", "golden", "keys.json")
 MAX_CLOCK_HZ = 2.4e9   # MI355X peak engine clock (MI355X_MICROARCH.md)
+DEFAULT_FB_WINDOW = 16  # fixed-base window of the tables for h: 0.66 GB per GPU (window 20 = 6.2 GB buys +0.9 %: window_sensitivity)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -135,6 +136,98 @@ def export_sample(path, eng, idx, l, x_enc, y_enc, draws, result):
         json.dump(doc, f)
 
 
+def interactive_protocol_leg(torch, eng, parties, ns, shard_inputs, x_enc, y_enc, expect, l, B, headline):
+    """Throughput of the batched INTERACTIVE protocol with draws=None and where its time goes.  `sessions` concurrent sessions
+    (one per shard context, each its own thread / stream / event loop -- the reference's session_id-namespaced parallel runs,
+    SC/test/unit/test_secure_comparison.py:803-835) mirror the headline's concurrent shards."""
+    import asyncio
+    from concurrent.futures import ThreadPoolExecutor
+
+    from protocols.secure_comparison_amd import Initiator, KeyHolder, wire
+    from protocols.secure_comparison_amd.batch import draw_alice, draw_bob
+    from protocols.secure_comparison_amd.communicator import InMemoryCommunicator
+
+    def run(device_tensors: bool, sessions: int, reps: int):
+        inputs = [(x_enc, y_enc)] if sessions == 1 else [(si[0], si[1]) for si in shard_inputs]
+        players = []
+        for ps in parties[:sessions]:
+            comm = InMemoryCommunicator(device_tensors=device_tensors)
+            # both players' scheme objects exist already (tables built: untimed set-up, as for the headline)
+            players.append((Initiator(l, comm, "keyholder", ps.alice_paillier, ps.alice_dgk),
+                            KeyHolder(l, comm.peer(), "initiator", ps.bob_paillier, ps.bob_dgk), ps))
+        caller = torch.cuda.current_stream()
+        for _, _, ps in players:      # concurrent sessions share the chip (batch-size policies of the library), like concurrent shards
+            ps.alice_paillier.engine.set_chip_share(sessions)
+
+        def session(i):
+            alice, bob, ps = players[i]
+
+            async def go():
+                res, _ = await asyncio.gather(alice.perform_secure_comparison_batch(*inputs[i], engine=ps.alice_paillier.engine),
+                                              bob.perform_secure_comparison_batch())
+                return res
+
+            if sessions == 1:
+                return asyncio.run(go())
+            with torch.cuda.device(eng.device), torch.cuda.stream(ps.stream):
+                ps.stream.wait_stream(caller)
+                res = asyncio.run(go())
+                res.record_stream(caller)
+                return res
+
+        def once():
+            if sessions == 1:
+                return session(0)
+            with ThreadPoolExecutor(max_workers=sessions) as pool:
+                parts = list(pool.map(session, range(sessions)))
+            for _, _, ps in players:
+                caller.wait_stream(ps.stream)
+            return torch.cat(parts, dim=0)
+
+        res = once()                                   # warm-up (program caches of the generator-sized launches)
+        torch.cuda.synchronize()
+        wire.reset_stats()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            res = once()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        for _, _, ps in players:
+            ps.alice_paillier.engine.set_chip_share(1)
+        dec = parties[0].bob_paillier.decrypt_raw_batch(res.contiguous())
+        ok = bool(((dec[:, 0] == expect) & (dec[:, 1:] == 0).all(dim=1)).all().item())
+        return dt, ok, {k: (v / reps) for k, v in wire.STATS.items()}
+
+    # the generator alone: all draws of one batch, both parties, timed with HIP events on the library's stream
+    ps0 = parties[0]
+    draw_alice(B, l, ps0.alice_paillier, ps0.alice_dgk), draw_bob(B, l, ps0.bob_paillier, ps0.bob_dgk)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    da, db = draw_alice(B, l, ps0.alice_paillier, ps0.alice_dgk), draw_bob(B, l, ps0.bob_paillier, ps0.bob_dgk)
+    e1.record()
+    torch.cuda.synchronize()
+    rng_s = e0.elapsed_time(e1) * 1e-3
+    rng_bytes = sum(t.numel() * t.element_size() for d in (da, db) for t in vars(d).values() if t is not None)
+    del da, db
+    dt1, ok1, _ = run(True, 1, 2)
+    dtn, okn, _ = (run(True, ns, 2) if ns > 1 else (dt1, ok1, None))
+    dth, okh, st = run(False, 1, 1)
+    return {
+        "value": B / dtn, "unit": "comparisons/s", "ratio_to_headline": B / dtn / (headline if headline else 1.0),
+        "sessions": ns, "correct": ok1 and okn and okh,
+        "single_session": {"value": B / dt1, "ms_per_batch": dt1 * 1e3},
+        "split_ms_per_batch": {"device_rng": rng_s * 1e3, "wire_pack_unpack": 0.0, "everything_else_gpu_and_host": (dt1 - rng_s) * 1e3},
+        "device_rng": {"bytes_per_comparison": rng_bytes / B, "GB_per_s": rng_bytes / rng_s / 1e9,
+                       "generator": "ChaCha20 block function (RFC 8439) in counter mode, keyed per context from the OS; rejection sampling, coins and shuffles on the device"},
+        "byte_transport": {"value": B / dth, "ms_per_batch": dth * 1e3, "wire_pack_ms": st["pack_s"] * 1e3, "wire_unpack_ms": st["unpack_s"] * 1e3,
+                           "wire_bytes_per_comparison": st["bytes"] / B,
+                           "note": "same protocol with every message serialized into one pinned host buffer (one device-to-host copy per array) and "
+                                   "parsed back (one host-to-device copy per array): what a transport between two processes adds"},
+        "note": "draws=None: all random inputs generated on the device inside the timed region; messages are the device arrays themselves "
+                "(InMemoryCommunicator.device_tensors); informational, never `value`"}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,7 +238,7 @@ def parse_args(argv=None):
     ap.add_argument("--pbits", type=int, default=2048)
     ap.add_argument("--dgk", default="", help="DGK key fixture (tests/golden/keys.json); default dgk_<pbits>_l<l>")
     ap.add_argument("--rbits", type=int, default=400)
-    ap.add_argument("--fb-window", type=int, default=20, help="window of the fixed-base table for h (2^w rows of 288 B per window: 6 GB at w = 20, HBM-resident)")
+    ap.add_argument("--fb-window", type=int, default=DEFAULT_FB_WINDOW, help="window of the fixed-base table for h (2^w rows of 288 B per window: 0.66 GB at w = 16, 6.2 GB at w = 20, HBM-resident)")
     ap.add_argument("--no-crt", action="store_true")
     ap.add_argument("--no-shuffle", action="store_true", help="leave the step-4i permutation out (do_shuffle=False)")
     ap.add_argument("--streams", type=int, default=0, help="concurrent shards per GPU (one library context, HIP stream and host thread each); 1 = a single stream; "
@@ -191,7 +284,11 @@ def main() -> None:
         import torch.distributed as dist  # noqa: F811
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        import datetime
+
+        # a rank that never arrives must not hang the others for torch's default half hour
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                timeout=datetime.timedelta(seconds=int(os.environ.get("SC_AMD_RENDEZVOUS_TIMEOUT_S", launcher.RENDEZVOUS_TIMEOUT_S))))
 
     keys = json.load(open(KEYS))
     l, B = args.l, args.batch
@@ -204,6 +301,7 @@ def main() -> None:
     use_crt = not args.no_crt
     eng = default_engine()
     ns = max(1, min(args.streams, B)) if args.streams > 0 else (2 if B >= 65536 else 1)
+    ns = launcher.host_threads_per_rank(world, ns)      # shard threads of all ranks together stay within the node's cores
     engines = [eng] + [Engine() for _ in range(1, ns)]
     for e_ in engines:
         e_.set_latency_mode(args.latency_mode)
@@ -242,14 +340,15 @@ def main() -> None:
         torch.cuda.synchronize()
 
     def make_step(party_sets):
+        """(step function, closer): the closer ends the shard threads and hands the chip back to single-stream policies."""
         if ns == 1:
             ps = party_sets[0]
-            return lambda: secure_comparison_batch(x_enc, y_enc, l, ps.alice_paillier, ps.alice_dgk, ps.bob_paillier, ps.bob_dgk, draws,
-                                                   randomize=True)
+            return (lambda: secure_comparison_batch(x_enc, y_enc, l, ps.alice_paillier, ps.alice_dgk, ps.bob_paillier, ps.bob_dgk, draws,
+                                                    randomize=True)), (lambda: None)
         runner = ConcurrentShards(party_sets)
-        return lambda: torch.cat(runner.run(shard_inputs, l, randomize=True), dim=0)
+        return (lambda: torch.cat(runner.run(shard_inputs, l, randomize=True), dim=0)), runner.close
 
-    step = make_step(parties)
+    step, close_step = make_step(parties)
 
     def gather(res):
         if dist is None:
@@ -304,6 +403,7 @@ def main() -> None:
     value = world * B * args.steps / elapsed
     if not all_correct(res):
         raise SystemExit("bench.py: decrypted results of the timed steps differ from x <= y")
+    close_step()      # the single-stream measurements below run with the policies of a context that has the chip to itself
     # outside the timed region: the same reassembly through the C ABI's own RCCL communicator (sc_comm_init / sc_allgather,
     # what a host without torch would call), compared with torch.distributed's gather.  Opt-in (--c-abi-gather: a second
     # communicator's rendezvous is not something the scaling run should depend on); reported, never fatal.
@@ -359,7 +459,7 @@ def main() -> None:
         abytes = algorithmic_bytes_per_comparison(l, args.pbits, dbits, args.rbits)
         # HBM traffic of the dominant launch from the committed PMC pass (rocprofv3 cannot run inside this process)
         traffic = None
-        for name in ("r02_dominant_kernel_traffic.json", "r01_dominant_kernel_traffic.json"):
+        for name in ("r03_dominant_kernel_traffic.json", "r02_dominant_kernel_traffic.json", "r01_dominant_kernel_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tpath) and B == 65536 and args.pbits == 2048 and l == 32 and use_crt:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
@@ -444,16 +544,23 @@ def main() -> None:
         if not args.no_extras and world == 1:
             # ---- how much of `value` hangs on the 6 GB window-20 table: the same step with smaller fixed-base windows
             sens = {str(args.fb_window): {"value": value, "table_bytes": table_bytes, "table_build_s": table_build_s}}
-            for w in (8, 16):
+            for w in (8, 16, 20):
                 if w == args.fb_window:
                     continue
                 ps_w, bs_w, tb_w = build_parties(w)
-                step_w = make_step(ps_w)
+                step_w, close_w = make_step(ps_w)
                 step_w()
                 dt_w, _ = timed(step_w, 2)
+                close_w()
                 sens[str(w)] = {"value": B * 2 / dt_w, "table_bytes": tb_w, "table_build_s": bs_w}
-                del ps_w, step_w
+                del ps_w, step_w, close_w
+                torch.cuda.empty_cache()
             out["window_sensitivity"] = sens
+            # ---- the real two-party batch protocol (reported, never `value`): Initiator / KeyHolder
+            # .perform_secure_comparison_batch with draws=None over the in-memory transport -- every random input drawn on the
+            # device by the library's CSPRNG inside the timed region, messages handed over as device arrays (or, second figure,
+            # serialized through one pinned host buffer per message as a real transport would need)
+            out["interactive_protocol"] = interactive_protocol_leg(torch, eng, parties, ns, shard_inputs, x_enc, y_enc, expect, l, B, value)
             # ---- online phase only (reported, never `value`): randomizers pre-generated into device pools (untimed), as the
             # reference pre-generates them in background workers (boot_randomness_generation, SC/initiator.py:205-210)
             gen = torch.Generator(device=eng.device)

@@ -17,7 +17,7 @@ import torch  # noqa: E402
 
 from protocols.secure_comparison_amd import DGK, InMemoryCommunicator, Initiator, KeyHolder, Paillier  # noqa: E402
 from protocols.secure_comparison_amd.keygen import next_prime  # noqa: E402
-from protocols.secure_comparison_amd.randomness import random_bits  # noqa: E402
+from protocols.secure_comparison_amd.randomness import uniform_below  # noqa: E402
 
 
 async def single_comparison() -> None:
@@ -46,8 +46,7 @@ async def batched(paillier: Paillier, dgk: DGK, count: int = 2048) -> None:
     def encrypt(v: torch.Tensor) -> torch.Tensor:
         words = torch.zeros((count, nw), dtype=torch.int32, device=dev)
         words[:, 0] = v.to(torch.int32)
-        rho = random_bits(paillier.public_key.n.bit_length() - 1, (count,), dev)
-        rho[:, 0] |= 1
+        rho = uniform_below(paillier.public_key.n, count, paillier.engine, nonzero=True)     # drawn on the device
         return paillier.randomize_batch(paillier.encrypt_raw_batch(words), rho)
 
     to_bob = InMemoryCommunicator()

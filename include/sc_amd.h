@@ -48,6 +48,8 @@ void sc_ctx_destroy(sc_ctx* ctx);
 int sc_ctx_set_stream(sc_ctx* ctx, void* hip_stream);   /* hipStream_t; NULL = default stream */
 int sc_ctx_synchronize(sc_ctx* ctx);
 const char* sc_last_error(sc_ctx* ctx);
+/* Bumped whenever an entry point is added or changes meaning; the binding checks it (round 1: 1, round 2 shipped 1 by mistake, round 3: 3). */
+#define SC_ABI_VERSION 3
 int sc_abi_version(void);
 /* Small-batch policy.  A modulus in an L = 18 configuration can be worked on by twice the lanes with 9 limbs each (same limb
  * arrays in memory): twice the waves, 1.8x shorter dependent chains, lower multiply-add density.  mode 0: never; 1 (default):
@@ -145,7 +147,8 @@ int sc_modexp_var_scatter(sc_ctx* ctx, int mod, const uint32_t* x_dptr, const ui
 /* out[i] = x[i]^-1 mod n (Montgomery's simultaneous inversion + an on-device binary extended GCD):
  * ct * -1 / int - ct / ct - ct (SC/initiator.py:254, 320, 371, 466, 478, 531, 559).
  * Synchronous.  On SC_ERR_NOT_INVERTIBLE *bad_index (nullable) is the index of a non-invertible element (found by testing
- * the members of the failing chunk individually) and sc_last_error() names it; `out` is unspecified then. */
+ * the members of the failing chunk individually) and sc_last_error() names it; `out` is unspecified then.
+ * `out` must not overlap `x` (SC_ERR_ARG): the operands are re-read on the error path. */
 int sc_modinv(sc_ctx* ctx, int mod, const uint32_t* x_dptr, uint32_t* out_dptr, uint64_t count,
               int64_t* bad_index);
 
@@ -192,6 +195,26 @@ int sc_dgk_step4(sc_ctx* ctx, int mod, int cst_g, int cst_ginv, int l, const uin
                  const uint32_t* beta_inv_dptr, const uint32_t* d_dptr, const uint32_t* d_inv_dptr,
                  const uint64_t* alpha_dptr, const uint64_t* alpha_tilde_dptr, const uint64_t* rsmall_dptr,
                  const uint64_t* delta_a_dptr, uint32_t* c_out_dptr, uint64_t count);
+
+/* ---- device-side CSPRNG: the random draws of a batch, generated where they are consumed ---------------- */
+/* The reference draws from Python's `secrets` (SC/initiator.py:223 permutation, :250 r, :420 delta_A, :512 rho_i) and the
+ * scheme packages draw the randomizers behind every .randomize() ([ext]).  A batch of 65536 comparisons needs ~0.3 GB of such
+ * draws per step; these entry points produce them on the device from a counter-mode generator: the ChaCha20 block function
+ * (RFC 8439 2.3), keystream(call, item) = ChaCha20_block(key, counter = 0, 1, .., nonce = (item, call_lo, call_hi)) read as
+ * little-endian words, `call` = number of generator calls on this context since it was seeded.  Asynchronous on the stream.
+ *   sc_rng_seed:         32-byte key from the caller (reproducible tests, known-answer vectors) or, with NULL, from the OS
+ *                        (getrandom); resets the call counter.  An unseeded context seeds itself from the OS on first use.
+ *   sc_rng_bits:         out[count][ceil(bits/32)]: uniform below 2^bits (DGK randomizer exponents).
+ *   sc_rng_below:        out[count][nwords]: uniform in [0, n) or, nonzero != 0, in [1, n), by rejection sampling on the device
+ *                        (r below N, rho_i in [1, u), Paillier randomizer bases in [1, N)); n must fill its top word.
+ *   sc_rng_coins:        out[count] uint64, each 0 or 1 (delta_A).
+ *   sc_rng_permutations: out[count][k] int64: one uniform permutation of 0 .. k-1 per item (Fisher-Yates with rejection-sampled
+ *                        indices; the step-4i shuffle, consumed by sc_modexp_var_scatter as a destination index). */
+int sc_rng_seed(sc_ctx* ctx, const uint8_t* key32_hptr /* nullable */);
+int sc_rng_bits(sc_ctx* ctx, int bits, uint32_t* out_dptr, uint64_t count);
+int sc_rng_below(sc_ctx* ctx, const uint32_t* n_hptr, int nwords, int nonzero, uint32_t* out_dptr, uint64_t count);
+int sc_rng_coins(sc_ctx* ctx, uint64_t* out_dptr, uint64_t count);
+int sc_rng_permutations(sc_ctx* ctx, int k, int64_t* out_dptr, uint64_t count);
 
 /* ---- multi-GPU ---------------------------------------------------------------------- */
 /* The comparisons of a batch are independent: every rank (one process and one context per GPU) runs all steps on its own block

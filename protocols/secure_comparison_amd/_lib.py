@@ -14,8 +14,12 @@ SYMBOLS = [
     "sc_mod_create", "sc_mod_words", "sc_exp_create", "sc_const_create", "sc_fbt_create", "sc_fbt_import", "sc_fbt_bytes",
     "sc_modmul", "sc_modmul_const", "sc_modmul_const_sel", "sc_modexp_shared", "sc_modexp_shared_sq", "sc_mod_supports_sq", "sc_modexp_shared_isone", "sc_modexp_shared_isone_any", "sc_fixedbase_pow", "sc_modexp_var", "sc_modexp_var_scatter",
     "sc_modinv", "sc_paillier_encrypt_raw", "sc_paillier_encrypt_raw_neg", "sc_paillier_l_mul", "sc_crt_combine", "sc_plain_alice", "sc_plain_bob", "sc_dgk_step4",
+    "sc_rng_seed", "sc_rng_bits", "sc_rng_below", "sc_rng_coins", "sc_rng_permutations",
     "sc_peak_probe", "sc_mac_counter", "sc_table_traffic_probe", "sc_ctx_set_latency_mode", "sc_ctx_set_onelane_mode", "sc_ctx_set_chip_share", "sc_comm_unique_id", "sc_comm_init", "sc_allgather", "sc_comm_destroy",
 ]
+
+
+ABI_VERSION = 3   # SC_ABI_VERSION of include/sc_amd.h
 
 
 class ScError(RuntimeError):
@@ -75,6 +79,11 @@ def load() -> C.CDLL:
         "sc_plain_alice": (i32, [vp, vp, vp, i32, i32, u64, vp, vp, vp, vp, vp]),
         "sc_plain_bob": (i32, [vp, vp, vp, i32, i32, u64, vp, vp, vp, vp]),
         "sc_dgk_step4": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64]),
+        "sc_rng_seed": (i32, [vp, vp]),
+        "sc_rng_bits": (i32, [vp, i32, vp, u64]),
+        "sc_rng_below": (i32, [vp, vp, i32, i32, vp, u64]),
+        "sc_rng_coins": (i32, [vp, vp, u64]),
+        "sc_rng_permutations": (i32, [vp, i32, vp, u64]),
         "sc_peak_probe": (i32, [vp, C.POINTER(C.c_double)]),
         "sc_mac_counter": (i32, [vp, i32, C.POINTER(C.c_double)]),
         "sc_table_traffic_probe": (i32, [vp, i32, vp, vp, u64, i32, i32, C.POINTER(C.c_int)]),
@@ -90,5 +99,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if lib.sc_abi_version() != ABI_VERSION:
+        raise ScError(f"{LIB_PATH} speaks ABI version {lib.sc_abi_version()}, this binding expects {ABI_VERSION}: rebuild the library")
     _lib = lib
     return lib

@@ -46,8 +46,36 @@ class BatchTrace:
     delta_b_enc: torch.Tensor | None = None
 
 
+def draw_alice(count: int, l: int, paillier: Paillier, dgk: DGK, source: str = "device", generator=None) -> BatchDraws:
+    """Alice's random inputs for `count` comparisons, drawn on the device (randomness.py): r below N (SC/initiator.py:250), the
+    coin delta_A (:420), rho_i in [1, u) (:512), the shuffle (:223), and the inputs of her 1 + (l+1) randomizations (:109,
+    :153-154; :205-210 scaled by the batch).  The key holder's fields stay None."""
+    from .randomness import random_bits, random_coins, random_permutations, uniform_below
+
+    e, n, u = paillier.engine, paillier.public_key.n, dgk.public_key.u
+    return BatchDraws(
+        r=uniform_below(n, count, e, source, generator), delta_a=random_coins(count, e, source, generator),
+        rhos=uniform_below(u, (l + 1) * count, e, source, generator, nonzero=True).reshape(l + 1, count, -1),
+        permutation=random_permutations(count, l + 1, e, source, generator),
+        rho_z=uniform_below(n, count, e, source, generator, nonzero=True), r_bob_dgk=None,
+        r_alice_dgk=random_bits(dgk.randomizer_bits, (l + 1, count), e, source, generator),
+        rho_zeta_1=None, rho_zeta_2=None, rho_delta_b=None)
+
+
+def draw_bob(count: int, l: int, paillier: Paillier, dgk: DGK, source: str = "device", generator=None) -> BatchDraws:
+    """The key holder's random inputs: the exponents of his (l+1) DGK randomizations (SC/keyholder.py:106-108) and the bases of
+    his 3 Paillier ones (:126-128) -- three row blocks of one array, so that they join again without a copy."""
+    from .randomness import random_bits, uniform_below
+
+    e = paillier.engine
+    rho = uniform_below(paillier.public_key.n, 3 * count, e, source, generator, nonzero=True)
+    return BatchDraws(r=None, delta_a=None, rhos=None, permutation=None, rho_z=None,
+                      r_bob_dgk=random_bits(dgk.randomizer_bits, (l + 1, count), e, source, generator), r_alice_dgk=None,
+                      rho_zeta_1=rho[:count], rho_zeta_2=rho[count:2 * count], rho_delta_b=rho[2 * count:])
+
+
 def boot_pools(count: int, l: int, alice_paillier: Paillier, alice_dgk: DGK, bob_paillier: Paillier, bob_dgk: DGK,
-               source: str = "os", generator=None) -> None:
+               source: str = "device", generator=None) -> None:
     """Pre-generate every randomizer `count` comparisons consume (the batched form of the two players'
     _start_randomness_generation: 1 + (l+1) for Alice, 3 + (l+1) for Bob, per comparison)."""
     alice_paillier.boot_randomness_generation_batch(count, source, generator)
@@ -164,9 +192,10 @@ class ConcurrentShards:
 
     def close(self) -> None:
         self._pool.shutdown(wait=True)
-        for p in self.parties:
-            if hasattr(p.alice_paillier.engine, "set_chip_share"):
-                p.alice_paillier.engine.set_chip_share(1)
+        for p in self.parties:     # the same set of engines __init__ touched
+            for scheme in (p.alice_paillier, p.alice_dgk, p.bob_paillier, p.bob_dgk):
+                if hasattr(scheme.engine, "set_chip_share"):
+                    scheme.engine.set_chip_share(1)
 
     def run(self, shards: list[tuple[torch.Tensor, torch.Tensor, BatchDraws]], l: int, randomize: bool | str = True) -> list[torch.Tensor]:
         """shards[i] = (x_enc, y_enc, draws) of shard i; returns the per-shard [[x <= y]] arrays."""

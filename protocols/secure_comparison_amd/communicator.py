@@ -25,13 +25,16 @@ class Communicator(Protocol):
 class InMemoryCommunicator:
     """Shared-mailbox transport for two players living in one event loop."""
 
-    def __init__(self, mailbox: dict[str, Any] | None = None, max_polls: int = 1_000_000) -> None:
+    def __init__(self, mailbox: dict[str, Any] | None = None, max_polls: int = 1_000_000, device_tensors: bool = True) -> None:
         self.mailbox: dict[str, Any] = {} if mailbox is None else mailbox
         self.max_polls = max_polls
+        # Both endpoints live in one process: a batch message may carry the device arrays themselves (wire.DeviceArrays) instead
+        # of bytes.  False makes the batch protocol serialize as it would for a real transport (one pinned host buffer).
+        self.device_tensors = device_tensors
 
     def peer(self) -> "InMemoryCommunicator":
         """A second endpoint on the same mailbox (hand it to the other player)."""
-        return InMemoryCommunicator(self.mailbox, self.max_polls)
+        return InMemoryCommunicator(self.mailbox, self.max_polls, self.device_tensors)
 
     async def send(self, party_id: str, message: Any, msg_id: str) -> None:
         if msg_id in self.mailbox:

@@ -2,6 +2,7 @@
 // Builds the micro-programs (sc_vm.h) for each batched operation and launches the gfx950 kernels.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <sys/random.h>
 
 #include <algorithm>
 #include <cstdarg>
@@ -16,6 +17,7 @@
 #include "../../../include/sc_amd.h"
 #include "sc_kernels.h"
 #include "sc_xgcd.h"
+#include "sc_rng.h"
 
 using namespace sc;
 
@@ -178,6 +180,9 @@ struct sc_ctx {
   std::map<int, int> onelane_twins;                         // mod -> context of the same modulus in the one-lane configuration
   std::map<int, int> pair_twins;                            // mod -> context of the same modulus in a pair-capable configuration
   std::map<int, uint32_t*> pair_consts;                     // mod -> 4 limb arrays: pair(R^2), pair(B R) for the pair arithmetic
+  RngKey rng_key;                                           // ChaCha20 key of the context's generator (sc_rng_seed)
+  bool rng_seeded = false;
+  uint64_t rng_call = 0;                                    // generator calls since seeding: part of every keystream's nonce
 };
 
 namespace {
@@ -526,7 +531,7 @@ int get_const_kred(sc_ctx* ctx, int mod, int* out_cid);
 // ================================================================================================
 extern "C" {
 
-int sc_abi_version(void) { return 1; }
+int sc_abi_version(void) { return SC_ABI_VERSION; }
 
 int sc_ctx_create(int device_id, sc_ctx** out_ctx) {
   if (!out_ctx) return SC_ERR_ARG;
@@ -1138,6 +1143,13 @@ static int modinv_find_member(sc_ctx* ctx, const Mod& m, const InvLevel& lv, int
 int sc_modinv(sc_ctx* ctx, int mod, const uint32_t* x, uint32_t* out, uint64_t count, int64_t* bad_index) {
   if (ctx && count == 0) return SC_OK;  // empty batch: nothing to do (pointers may be null)
   if (!valid_mod(ctx, mod) || !x || !out) return fail(ctx, SC_ERR_ARG, "sc_modinv: bad argument");
+  {
+    // The down-sweeps are queued before the verdicts are read, and the error path re-reads the operands to name the bad
+    // element: `out` must not overlap `x` (an in-place call would have overwritten them with garbage by then).
+    const size_t bytes = (size_t)count * ctx->mods[mod].nwords * 4;
+    const char *xb = (const char*)x, *ob = (const char*)out;
+    if (xb < ob + bytes && ob < xb + bytes) return fail(ctx, SC_ERR_ARG, "sc_modinv: out overlaps x (in-place inversion is not supported)");
+  }
   if (bad_index) *bad_index = -1;
   InvPending pend;
   int rc = modinv_rec(ctx, mod, x, out, count, &pend, 0);
@@ -1569,6 +1581,90 @@ int sc_comm_destroy(sc_ctx* ctx) {
   const int rc = api ? api->CommDestroy(ctx->comm) : 0;
   ctx->comm = nullptr; ctx->comm_nranks = 0;
   return rc ? rccl_fail(ctx, api, "ncclCommDestroy", rc) : SC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Device-side CSPRNG (sc_rng.h): the random draws of a batch are generated where they are consumed.
+// ------------------------------------------------------------------------------------------------
+int sc_rng_seed(sc_ctx* ctx, const uint8_t* key32_hptr) {
+  if (!ctx) return SC_ERR_ARG;
+  uint8_t buf[32];
+  if (key32_hptr) {
+    memcpy(buf, key32_hptr, 32);
+  } else {
+    size_t got = 0;
+    while (got < 32) {
+      const ssize_t r = getrandom(buf + got, 32 - got, 0);
+      if (r <= 0) return fail(ctx, SC_ERR_HIP, "sc_rng_seed: the operating system's random source failed");
+      got += (size_t)r;
+    }
+  }
+  for (int i = 0; i < 8; i++)
+    ctx->rng_key.k[i] = (uint32_t)buf[4 * i] | ((uint32_t)buf[4 * i + 1] << 8) | ((uint32_t)buf[4 * i + 2] << 16) | ((uint32_t)buf[4 * i + 3] << 24);
+  memset(buf, 0, sizeof buf);
+  ctx->rng_seeded = true;
+  ctx->rng_call = 0;
+  return SC_OK;
+}
+
+// every generator call: seeded context (from the OS on first use), at most 2^32 items (the item index is one nonce word), and a
+// call number of its own
+static int rng_begin(sc_ctx* ctx, uint64_t count, const void* out, const char* who, uint64_t* call) {
+  if (!ctx) return SC_ERR_ARG;
+  if (!out) return fail(ctx, SC_ERR_ARG, "%s: no output array", who);
+  if (count > 0xffffffffull) return fail(ctx, SC_ERR_ARG, "%s: at most 2^32 - 1 items per call", who);
+  if (!ctx->rng_seeded) { int rc = sc_rng_seed(ctx, nullptr); if (rc) return rc; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  *call = ctx->rng_call++;
+  return SC_OK;
+}
+
+int sc_rng_bits(sc_ctx* ctx, int bits, uint32_t* out, uint64_t count) {
+  if (ctx && count == 0) return SC_OK;
+  if (ctx && bits <= 0) return fail(ctx, SC_ERR_ARG, "sc_rng_bits: bits must be positive");
+  uint64_t call;
+  int rc = rng_begin(ctx, count, out, "sc_rng_bits", &call); if (rc) return rc;
+  hipLaunchKernelGGL(k_rng_bits, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rng_key, call, bits, (bits + 31) / 32, out, count);
+  HIPCHK(ctx, hipGetLastError());
+  return SC_OK;
+}
+
+int sc_rng_below(sc_ctx* ctx, const uint32_t* n_hptr, int nwords, int nonzero, uint32_t* out, uint64_t count) {
+  if (ctx && count == 0) return SC_OK;
+  if (ctx && (!n_hptr || nwords <= 0)) return fail(ctx, SC_ERR_ARG, "sc_rng_below: bad bound");
+  if (!ctx) return SC_ERR_ARG;
+  Big n(n_hptr, n_hptr + nwords);
+  const int nbits = big_bits(n);
+  if (nbits == 0 || (nonzero && nbits == 1)) return fail(ctx, SC_ERR_ARG, "sc_rng_below: empty range");
+  const int nw = (nbits + 31) / 32;
+  if (nw != nwords) return fail(ctx, SC_ERR_ARG, "sc_rng_below: the bound must fill its top word (nwords = %d, bound has %d words)", nwords, nw);
+  uint64_t call;
+  int rc = rng_begin(ctx, count, out, "sc_rng_below", &call); if (rc) return rc;
+  uint32_t* d_n = nullptr;
+  rc = device_n_half(ctx, n_hptr, nwords, &d_n); if (rc) return rc;
+  hipLaunchKernelGGL(k_rng_below, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rng_key, call, d_n, nbits, nw, nonzero ? 1 : 0, out, count);
+  HIPCHK(ctx, hipGetLastError());
+  return SC_OK;
+}
+
+int sc_rng_coins(sc_ctx* ctx, uint64_t* out, uint64_t count) {
+  if (ctx && count == 0) return SC_OK;
+  uint64_t call;
+  int rc = rng_begin(ctx, (count + 511) / 512, out, "sc_rng_coins", &call); if (rc) return rc;
+  const uint64_t threads = (count + 511) / 512;
+  hipLaunchKernelGGL(k_rng_coins, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rng_key, call, out, count);
+  HIPCHK(ctx, hipGetLastError());
+  return SC_OK;
+}
+
+int sc_rng_permutations(sc_ctx* ctx, int k, int64_t* out, uint64_t count) {
+  if (ctx && count == 0) return SC_OK;
+  if (ctx && (k < 1 || k > 256)) return fail(ctx, SC_ERR_ARG, "sc_rng_permutations: 1 <= k <= 256");
+  uint64_t call;
+  int rc = rng_begin(ctx, count, out, "sc_rng_permutations", &call); if (rc) return rc;
+  hipLaunchKernelGGL(k_rng_perm, dim3((unsigned)((count + 63) / 64)), dim3(64), (size_t)64 * k, ctx->stream, ctx->rng_key, call, k, out, count);
+  HIPCHK(ctx, hipGetLastError());
+  return SC_OK;
 }
 
 int sc_peak_probe(sc_ctx* ctx, double* out_mac_per_s) {

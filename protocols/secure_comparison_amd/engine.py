@@ -83,7 +83,8 @@ class Engine:
         raise ScError(f"{msg} (status {rc})")
 
     def _sync_stream(self) -> None:
-        self.lib.sc_ctx_set_stream(self.ctx, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        # a failed switch leaves the context on its previous stream, unordered against torch's current one: never ignore it
+        self._check(self.lib.sc_ctx_set_stream(self.ctx, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
 
     @staticmethod
     def _ptr(t: torch.Tensor | None) -> C.c_void_p:
@@ -454,6 +455,45 @@ class Engine:
     def comm_destroy(self) -> None:
         self._check(self.lib.sc_comm_destroy(self.ctx))
         self._comm_nranks = 0
+
+    # ------------------------------------------------------------------ device-side CSPRNG (sc_rng_*)
+    def rng_seed(self, key: bytes | None = None) -> None:
+        """Key the context's generator: 32 bytes from the caller (reproducible tests) or, with None, from the OS.  An unseeded
+        engine seeds itself from the OS on its first draw."""
+        if key is not None and len(key) != 32:
+            raise ValueError("the generator key has 32 bytes")
+        buf = None if key is None else (C.c_char * 32).from_buffer_copy(key)
+        self._check(self.lib.sc_rng_seed(self.ctx, None if buf is None else C.cast(buf, C.c_void_p)))
+
+    def rng_bits(self, bits: int, count: int) -> torch.Tensor:
+        """[count][ceil(bits/32)] words, each item uniform below 2^bits."""
+        out = self.empty(count, (bits + 31) // 32)
+        self._sync_stream()
+        self._check(self.lib.sc_rng_bits(self.ctx, int(bits), self._ptr(out), count))
+        return out
+
+    def rng_below(self, n: int, count: int, nonzero: bool = False) -> torch.Tensor:
+        """[count][nwords(n)] words, each item uniform in [0, n) (or [1, n)): rejection sampling on the device."""
+        nw = (n.bit_length() + 31) // 32
+        arr, p = self._host_n_words(n, nw)
+        out = self.empty(count, nw)
+        self._sync_stream()
+        self._check(self.lib.sc_rng_below(self.ctx, p, nw, int(bool(nonzero)), self._ptr(out), count))
+        return out
+
+    def rng_coins(self, count: int) -> torch.Tensor:
+        """int64 [count], each 0 or 1."""
+        out = torch.empty((count,), dtype=torch.int64, device=self.device)
+        self._sync_stream()
+        self._check(self.lib.sc_rng_coins(self.ctx, self._ptr(out), count))
+        return out
+
+    def rng_permutations(self, k: int, count: int) -> torch.Tensor:
+        """int64 [count][k]: one uniform permutation of range(k) per item."""
+        out = torch.empty((count, k), dtype=torch.int64, device=self.device)
+        self._sync_stream()
+        self._check(self.lib.sc_rng_permutations(self.ctx, int(k), self._ptr(out), count))
+        return out
 
     def peak_probe(self) -> float:
         v = C.c_double()

@@ -92,19 +92,22 @@ class Initiator:
         return Initiator.step_7(zeta_1_enc, zeta_2_enc, r, l, beta_lt_alpha_enc, pai)
 
     async def perform_secure_comparison_batch(self, x_enc: torch.Tensor, y_enc: torch.Tensor, draws=None,
-                                              source: str = "os", engine=None) -> torch.Tensor:
-        """B comparisons at once over the same four message exchanges, with batches on the wire as raw word arrays
-        (wire.py).  `draws` (batch.BatchDraws; Alice's fields) injects the randomness; otherwise it is drawn from the
-        OS CSPRNG and the randomizers come from device-side pools booted here (1 Paillier + (l+1) DGK per comparison,
-        SC/initiator.py:205-210 scaled by B).  x_enc, y_enc: [B][2nw] Paillier ciphertexts."""
+                                              source: str = "device", engine=None, generator=None) -> torch.Tensor:
+        """B comparisons at once over the same four message exchanges, with batches on the wire as whole arrays
+        (wire.py: the device arrays themselves when the transport's endpoints share a GPU, one pinned byte buffer otherwise).
+        `draws` (batch.BatchDraws; Alice's fields) injects the randomness; otherwise every draw of SC/initiator.py:250, :420,
+        :512, :223 and the 1 + (l+1) randomizer inputs per comparison (:205-210 scaled by B) are generated ON THE DEVICE by the
+        engine's CSPRNG (`source="device"`; "torch" + `generator` = seeded, for reproducible runs) and consumed by the same fused
+        launches as injected draws.  x_enc, y_enc: [B][2nw] Paillier ciphertexts."""
         from . import wire
-        from .randomness import random_bits_u64, random_permutations, uniform_below
+        from .batch import draw_alice
 
         if self.communicator is None:
             raise ValueError("Communicator not properly initialized.")
+        comm = self.communicator
         self.session_id += 1
         sid = self.session_id
-        got_p, got_d = wire.unpack_public_schemes(await self.communicator.recv(self.other_party, msg_id=f"schemes_batch_session_{sid}"), engine)
+        got_p, got_d = wire.unpack_public_schemes(await comm.recv(self.other_party, msg_id=f"schemes_batch_session_{sid}"), engine)
         if self._scheme_paillier is None:
             self._scheme_paillier = got_p
         elif self._scheme_paillier != got_p:
@@ -119,31 +122,22 @@ class Initiator:
         wire.expect_array(x_enc, (count, 2 * nw_p), "x_enc")
         wire.expect_array(y_enc, (count, 2 * nw_p), "y_enc")
         if draws is None:
-            pai.boot_randomness_generation_batch(count, source)
-            dgk.boot_randomness_generation_batch((l + 1) * count, source)
-            u = dgk.public_key.u
-            rhos = uniform_below(u, (l + 1) * count, dev, source, nonzero=True).reshape(l + 1, count, -1)
-            r, delta_a = uniform_below(pai.public_key.n, count, dev, source), random_bits_u64(count, dev, source)
-            perm = random_permutations(count, l + 1, dev, source)
-        else:
-            r, delta_a, rhos, perm = draws.r, draws.delta_a, draws.rhos, draws.permutation
-        z_enc, plain = Initiator.step_1_batch(x_enc, y_enc, l, pai, r)
-        z_enc = pai.randomize_from_pool_batch(z_enc) if draws is None else pai.randomize_batch(z_enc, draws.rho_z)
-        await self.communicator.send(self.other_party, wire.pack_tensor(z_enc), msg_id=f"step_1_batch_session_{sid}")
-        d_enc, beta_enc = wire.unpack_many(await self.communicator.recv(self.other_party, msg_id=f"step_4b_batch_session_{sid}"), dev, expect=2)
+            draws = draw_alice(count, l, pai, dgk, source, generator)
+        z_enc, plain = Initiator.step_1_batch(x_enc, y_enc, l, pai, draws.r)
+        z_enc = pai.randomize_batch(z_enc, draws.rho_z)
+        await comm.send(self.other_party, wire.outgoing(comm, z_enc), msg_id=f"step_1_batch_session_{sid}")
+        d_enc, beta_enc = wire.incoming(await comm.recv(self.other_party, msg_id=f"step_4b_batch_session_{sid}"), dev, expect=2)
         d_enc = wire.expect_array(d_enc, (count, nw_d), "[d]")                      # sizes come from this side's l and B,
         beta_enc = wire.expect_array(beta_enc, (l, count, nw_d), "[beta_i]")        # never from the message
-        c_h = Initiator.step_4c_to_4h_batch(d_enc, beta_enc, plain, delta_a, dgk)
-        c = Initiator.step_4i_batch(c_h, dgk, rhos, perm, None if draws is None else draws.r_alice_dgk)
-        if draws is None:
-            lp1, _, nw = c.shape
-            c = dgk.randomize_from_pool_batch(c.reshape(lp1 * count, nw)).reshape(lp1, count, nw)
-        await self.communicator.send(self.other_party, wire.pack_tensor(c), msg_id=f"step_4i_batch_session_{sid}")
-        zeta_1, zeta_2, delta_b_enc = wire.unpack_many(await self.communicator.recv(self.other_party, msg_id=f"step_5_batch_session_{sid}"), dev, expect=3)
+        c_h = Initiator.step_4c_to_4h_batch(d_enc, beta_enc, plain, draws.delta_a, dgk)
+        c = Initiator.step_4i_batch(c_h, dgk, draws.rhos, draws.permutation, draws.r_alice_dgk)
+        if draws.permutation is not None and not bool(Initiator.permutation_is_valid(draws.permutation)):
+            raise ValueError("permutation: a row is not a permutation of the l + 1 positions")   # before anything is sent
+        await comm.send(self.other_party, wire.outgoing(comm, c), msg_id=f"step_4i_batch_session_{sid}")
+        zeta_1, zeta_2, delta_b_enc = wire.incoming(await comm.recv(self.other_party, msg_id=f"step_5_batch_session_{sid}"), dev, expect=3)
         zeta_1, zeta_2, delta_b_enc = (wire.expect_array(t, (count, 2 * nw_p), name) for t, name in
                                        ((zeta_1, "[[zeta_1]]"), (zeta_2, "[[zeta_2]]"), (delta_b_enc, "[[delta_B]]")))
-        blta = Initiator.step_6_batch(delta_a, delta_b_enc, pai)
-        return Initiator.step_7_batch(zeta_1, zeta_2, plain, l, blta, pai)
+        return Initiator.step_6_7_batch(draws.delta_a, delta_b_enc, zeta_1, zeta_2, plain, l, pai)   # one inversion pass
 
     async def receive_encryption_schemes(self, session_id: int = 1) -> None:
         """Receive Bob's public schemes; a pre-set scheme must match (SC/initiator.py:177-203)."""
@@ -302,21 +296,31 @@ class Initiator:
         e = scheme_dgk.engine
         lp1, count, nw = c_is_enc.shape
         ubits = (scheme_dgk.public_key.u - 1).bit_length()
-        dest = None
+        dest, out = None, None
         if permutation is not None:
             # the shuffle rides in the store of the blinding launch: blinded plane j of comparison b goes to output plane
             # k with permutation[b][k] == j, i.e. to flat row inverse[b][j] * B + b
             if tuple(permutation.shape) != (count, lp1) or permutation.dtype != torch.int64:
                 raise ValueError(f"permutation: expected int64 [{count}][{lp1}], got {permutation.dtype} {tuple(permutation.shape)}")
-            # entries are clamped into range instead of checked (a check would cost a host round trip in the middle of the step);
-            # a row that is not a permutation only scrambles that comparison's own vector -- the store never leaves the array
+            # entries are clamped into range here and CHECKED lazily (permutation_is_valid: a device flag the caller reads where it
+            # synchronises anyway -- before the send in the interactive protocol); the scatter target is zero-filled, so a row that
+            # is not a permutation leaves zero planes in that comparison's own vector, never stale device memory
             planes = torch.arange(lp1, device=permutation.device, dtype=torch.int64).expand(count, lp1)
             inverse = torch.zeros_like(permutation).scatter_(1, permutation.clamp(0, lp1 - 1), planes)
             dest = (inverse.t() * count + torch.arange(count, device=permutation.device, dtype=torch.int64)).reshape(-1).contiguous()
+            out = torch.zeros((lp1 * count, nw), dtype=torch.int32, device=c_is_enc.device)
         flat = e.modexp_var(scheme_dgk.mod_n, c_is_enc.reshape(lp1 * count, nw), rhos.reshape(lp1 * count, -1), ubits,
                             scheme_dgk.fb_h if randomizer_exponents is not None else None,
-                            None if randomizer_exponents is None else randomizer_exponents.reshape(lp1 * count, -1), dest=dest)
+                            None if randomizer_exponents is None else randomizer_exponents.reshape(lp1 * count, -1), dest=dest, out=out)
         return flat.reshape(lp1, count, nw)
+
+    @staticmethod
+    def permutation_is_valid(permutation: torch.Tensor) -> torch.Tensor:
+        """Device flag (0-dim bool): every row of `permutation` ([B][k] int64) is a permutation of range(k).  Reading it
+        synchronises; step_4i_batch itself never does."""
+        k = permutation.shape[1]
+        ref = torch.arange(k, device=permutation.device, dtype=torch.int64)
+        return (torch.sort(permutation, dim=1).values == ref).all()
 
     @staticmethod
     def step_6_batch(delta_a: torch.Tensor, delta_b_enc: torch.Tensor, scheme_paillier: Paillier) -> torch.Tensor:

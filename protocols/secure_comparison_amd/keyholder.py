@@ -79,49 +79,39 @@ class KeyHolder:
             ct.randomize()
         await self.communicator.send(self.other_party, (zeta_1_enc, zeta_2_enc, delta_b_enc), msg_id=f"step_5_session_{sid}")
 
-    async def perform_secure_comparison_batch(self, draws=None, source: str = "os") -> None:
+    async def perform_secure_comparison_batch(self, draws=None, source: str = "device", generator=None) -> None:
         """Bob's side of Initiator.perform_secure_comparison_batch.  `draws` (batch.BatchDraws; Bob's fields) injects
-        the randomizer inputs; otherwise 3 Paillier + (l+1) DGK randomizers per comparison come from device pools
-        (SC/keyholder.py:174-179 scaled by B)."""
+        the randomizer inputs; otherwise the 3 Paillier + (l+1) DGK randomizer inputs per comparison (SC/keyholder.py:174-179
+        scaled by B) are drawn on the device by the engine's CSPRNG and consumed by the same fused launches."""
         from . import wire
+        from ._views import cat_rows
+        from .batch import draw_bob
 
         if self.communicator is None:
             raise ValueError("Communicator not properly initialized.")
+        comm = self.communicator
         self.session_id += 1
         sid = self.session_id
         pai, dgk, l = self.scheme_paillier, self.scheme_dgk, self.l_maximum_bit_length
-        await self.communicator.send(self.other_party, wire.pack_public_schemes(pai, dgk), msg_id=f"schemes_batch_session_{sid}")
+        await comm.send(self.other_party, wire.pack_public_schemes(pai, dgk), msg_id=f"schemes_batch_session_{sid}")
         dev = pai.engine.device
-        z_enc = wire.unpack_tensor(await self.communicator.recv(self.other_party, msg_id=f"step_1_batch_session_{sid}"), dev)
-        if z_enc.dim() != 2:
-            raise ValueError(f"[[z]]: received shape {tuple(z_enc.shape)}, expected [B][{2 * pai.mod_n.nwords}]")
+        (z_enc,) = wire.incoming(await comm.recv(self.other_party, msg_id=f"step_1_batch_session_{sid}"), dev, expect=1)
+        if not isinstance(z_enc, torch.Tensor) or z_enc.dim() != 2:
+            raise ValueError(f"[[z]]: received shape {tuple(getattr(z_enc, 'shape', ()))}, expected [B][{2 * pai.mod_n.nwords}]")
         count = z_enc.shape[0]                       # the batch size is Alice's to choose; everything else is checked against it
         z_enc = wire.expect_array(z_enc, (count, 2 * pai.mod_n.nwords), "[[z]]")
         if draws is None:
-            pai.boot_randomness_generation_batch(3 * count, source)
-            dgk.boot_randomness_generation_batch((l + 1) * count, source)
+            draws = draw_bob(count, l, pai, dgk, source, generator)
         plain = KeyHolder.step_2_batch(z_enc, l, pai)
-        d_enc, beta_enc = KeyHolder.step_4a_4b_batch(plain, l, dgk, pai, None if draws is None else draws.r_bob_dgk)
-        if draws is None:
-            nw = d_enc.shape[-1]
-            from ._views import cat_rows
-
-            rnd = dgk.randomize_from_pool_batch(cat_rows([d_enc.reshape(1, count, nw), beta_enc]).reshape((l + 1) * count, nw))
-            rnd = rnd.reshape(l + 1, count, nw)
-            d_enc, beta_enc = rnd[0].contiguous(), rnd[1:].contiguous()
-        await self.communicator.send(self.other_party, wire.pack_many(d_enc, beta_enc), msg_id=f"step_4b_batch_session_{sid}")
-        c_enc = wire.unpack_tensor(await self.communicator.recv(self.other_party, msg_id=f"step_4i_batch_session_{sid}"), dev)
+        d_enc, beta_enc = KeyHolder.step_4a_4b_batch(plain, l, dgk, pai, draws.r_bob_dgk)
+        await comm.send(self.other_party, wire.outgoing(comm, d_enc, beta_enc), msg_id=f"step_4b_batch_session_{sid}")
+        (c_enc,) = wire.incoming(await comm.recv(self.other_party, msg_id=f"step_4i_batch_session_{sid}"), dev, expect=1)
         c_enc = wire.expect_array(c_enc, (l + 1, count, dgk.mod_n.nwords), "[c_i]")
         delta_b = KeyHolder.step_4j_batch(c_enc, dgk)
-        from ._views import cat_rows
-
         triple = cat_rows(KeyHolder.step_5_batch(plain, delta_b, pai))
-        if draws is None:
-            triple = pai.randomize_from_pool_batch(triple)
-        else:
-            triple = pai.randomize_batch(triple, torch.cat([draws.rho_zeta_1, draws.rho_zeta_2, draws.rho_delta_b], dim=0))
-        await self.communicator.send(self.other_party, wire.pack_many(triple[:count], triple[count:2 * count], triple[2 * count:]),
-                                     msg_id=f"step_5_batch_session_{sid}")
+        triple = pai.randomize_batch(triple, cat_rows([draws.rho_zeta_1, draws.rho_zeta_2, draws.rho_delta_b]))
+        await comm.send(self.other_party, wire.outgoing(comm, triple[:count], triple[count:2 * count], triple[2 * count:]),
+                        msg_id=f"step_5_batch_session_{sid}")
 
     async def make_and_send_encryption_schemes(self, session_id: int = 1, key_length_paillier: int = 2048,
                                                v_bits_dgk: int = 160, n_bits_dgk: int = 2048) -> None:

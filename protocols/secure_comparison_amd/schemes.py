@@ -248,7 +248,7 @@ class _Scheme:
         self._batch_pool = None
 
     # ---- device-resident randomizer pools for whole batches
-    def boot_randomness_generation_batch(self, amount: int, source: str = "os", generator=None) -> None:
+    def boot_randomness_generation_batch(self, amount: int, source: str = "device", generator=None) -> None:
         """Pre-generate `amount` randomizers on the GPU and keep them as a device array (the batched analogue of
         boot_randomness_generation: the expensive exponentiations happen ahead of the protocol run)."""
         if amount <= 0:
@@ -257,7 +257,7 @@ class _Scheme:
         pool = getattr(self, "_batch_pool", None)
         self._batch_pool = fresh if pool is None or pool.shape[0] == 0 else torch.cat([pool, fresh], dim=0)
 
-    def take_randomness_batch(self, amount: int, source: str = "os", generator=None) -> torch.Tensor:
+    def take_randomness_batch(self, amount: int, source: str = "device", generator=None) -> torch.Tensor:
         pool = getattr(self, "_batch_pool", None)
         have = 0 if pool is None else pool.shape[0]
         if have < amount:
@@ -456,10 +456,10 @@ class Paillier(_Scheme):
         rho = self.engine.upload([1 + secrets.randbelow(n - 1) for _ in range(amount)], self.mod_n.nwords)
         return self.engine.download(self.randomizer_batch(rho))
 
-    def _generate_randomness_batch(self, amount: int, source: str = "os", generator=None) -> torch.Tensor:
+    def _generate_randomness_batch(self, amount: int, source: str = "device", generator=None) -> torch.Tensor:
         from .randomness import uniform_below
 
-        rho = uniform_below(self.public_key.n, amount, self.engine.device, source, generator, nonzero=True)
+        rho = uniform_below(self.public_key.n, amount, self.engine, source, generator, nonzero=True)
         return self.randomizer_batch(rho)
 
     def _apply_randomness(self, value: int, randomness: int) -> int:
@@ -685,10 +685,10 @@ class DGK(_Scheme):
         r = self.engine.upload([secrets.randbits(self.randomizer_bits) for _ in range(amount)], ew)
         return self.engine.download(self.randomize_batch(None, r))
 
-    def _generate_randomness_batch(self, amount: int, source: str = "os", generator=None) -> torch.Tensor:
+    def _generate_randomness_batch(self, amount: int, source: str = "device", generator=None) -> torch.Tensor:
         from .randomness import random_bits
 
-        return self.randomize_batch(None, random_bits(self.randomizer_bits, (amount,), self.engine.device, source, generator))
+        return self.randomize_batch(None, random_bits(self.randomizer_bits, (amount,), self.engine, source, generator))
 
     def _apply_randomness(self, value: int, randomness: int) -> int:
         return self._mul_values(value, randomness)

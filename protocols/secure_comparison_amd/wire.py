@@ -1,16 +1,31 @@
-"""Compact binary wire format for ciphertext batches.
+"""Wire format for ciphertext batches.
 
 The reference sends Python scheme / ciphertext objects through its transport's serializer, one object per
-ciphertext (SC/test/conftest.py:182,198).  A batch of B comparisons moves ~19 KB per comparison, so batches travel
-as raw little-endian word arrays with a 16+ byte header instead:
+ciphertext (SC/test/conftest.py:182,198).  A batch of B comparisons moves ~19 KB per comparison (0.55 GB for each per-bit
+vector at B = 65536), so a batch travels in one of two forms, chosen by what the transport can carry:
 
-    magic "SCB1" | dtype code u8 | ndim u8 | reserved u16 | dims (ndim x u64) | payload
+* **device hand-over** -- a transport whose two endpoints live in one process on one GPU (`communicator.device_tensors` is
+  true: InMemoryCommunicator) gets a `DeviceArrays` message: the device tensors themselves plus an event recorded on the
+  sender's stream, which the receiver's stream waits for.  No byte ever leaves HBM.
+* **bytes** -- any other transport gets ONE buffer per message: header(s) and payload(s) are written into a single pinned host
+  buffer by one device-to-host copy per array (no intermediate numpy copies, no concatenation), and handed over as a
+  `memoryview`:
 
-Public keys travel as a small JSON document (integers as hex)."""
+      message  = count u32 | { length u64 | array }*            (pack_many)
+      array    = magic "SCB1" | dtype code u8 | ndim u8 | reserved u16 | dims (ndim x u64) | payload (little-endian words)
+
+  The receiver wraps the payload in place (`torch.frombuffer`) and issues one host-to-device copy per array.
+
+Either way nothing in a message is trusted: shapes and dtypes are checked against the bytes that arrived and then against
+what this party's own parameters (l, B, key sizes) dictate (`expect_array`).  Public keys travel as a small JSON document
+(integers as hex).  `STATS` accumulates the seconds and bytes spent packing / unpacking (bench.py reports the split)."""
 from __future__ import annotations
 
 import json
 import struct
+import time
+from dataclasses import dataclass
+from typing import Any, Sequence
 
 import numpy as np
 import torch
@@ -18,43 +33,144 @@ import torch
 MAGIC = b"SCB1"
 _DTYPES = {0: (torch.int32, np.dtype("<i4")), 1: (torch.int64, np.dtype("<i8")), 2: (torch.uint8, np.dtype("u1"))}
 _CODES = {t: c for c, (t, _) in _DTYPES.items()}
+MAX_NDIM = 4
+STATS = {"pack_s": 0.0, "unpack_s": 0.0, "bytes": 0, "device_arrays": 0}
 
 
-def pack_tensor(t: torch.Tensor) -> bytes:
+def reset_stats() -> None:
+    STATS.update(pack_s=0.0, unpack_s=0.0, bytes=0, device_arrays=0)
+
+
+@dataclass
+class DeviceArrays:
+    """A batch message that never leaves the GPU: the arrays themselves, to be treated as read-only by the receiver, and the
+    event after which they are complete."""
+
+    arrays: tuple[torch.Tensor, ...]
+    ready: Any = None          # torch.cuda.Event recorded on the sender's stream (None for CPU tensors)
+
+
+def carries_device_arrays(communicator: Any) -> bool:
+    return bool(getattr(communicator, "device_tensors", False))
+
+
+def _header(t: torch.Tensor) -> bytes:
     if t.dtype not in _CODES:
         raise ValueError(f"unsupported dtype {t.dtype}")
-    arr = t.detach().contiguous().cpu().numpy()
-    head = MAGIC + struct.pack("<BBH", _CODES[t.dtype], arr.ndim, 0) + struct.pack(f"<{arr.ndim}Q", *arr.shape)
-    return head + arr.astype(_DTYPES[_CODES[t.dtype]][1], copy=False).tobytes()
+    if t.dim() > MAX_NDIM:
+        raise ValueError(f"at most {MAX_NDIM} dimensions")
+    return MAGIC + struct.pack("<BBH", _CODES[t.dtype], t.dim(), 0) + struct.pack(f"<{t.dim()}Q", *t.shape)
 
 
-MAX_NDIM = 4
+def _pack(tensors: Sequence[torch.Tensor], framed: bool) -> memoryview:
+    """One host buffer for the whole message; every payload lands in it by a single copy from wherever the array lives."""
+    t0 = time.perf_counter()
+    heads = [_header(t) for t in tensors]
+    sizes = [len(h) + t.numel() * t.element_size() for h, t in zip(heads, tensors)]
+    total = (4 + sum(8 + s for s in sizes)) if framed else sizes[0]
+    pinned = any(t.is_cuda for t in tensors)
+    buf = torch.empty(total, dtype=torch.uint8, pin_memory=pinned)
+    raw = buf.numpy()
+    off = 0
+    if framed:
+        raw[0:4] = np.frombuffer(struct.pack("<I", len(tensors)), dtype=np.uint8)
+        off = 4
+    for h, t, s in zip(heads, tensors, sizes):
+        if framed:
+            raw[off:off + 8] = np.frombuffer(struct.pack("<Q", s), dtype=np.uint8)
+            off += 8
+        raw[off:off + len(h)] = np.frombuffer(h, dtype=np.uint8)
+        nbytes = s - len(h)
+        if nbytes:
+            # the payload region viewed as bytes of the array's own dtype: one (device-to-)host copy, straight into place
+            buf[off + len(h):off + s].copy_(t.detach().contiguous().reshape(-1).view(torch.uint8), non_blocking=False)
+        off += s
+    STATS["pack_s"] += time.perf_counter() - t0
+    STATS["bytes"] += total
+    return memoryview(raw)
 
 
-def unpack_tensor(buf: bytes, device: torch.device | str = "cpu") -> torch.Tensor:
+def pack_tensor(t: torch.Tensor) -> memoryview:
+    return _pack([t], framed=False)
+
+
+def pack_many(*tensors: torch.Tensor) -> memoryview:
+    return _pack(tensors, framed=True)
+
+
+def outgoing(communicator: Any, *tensors: torch.Tensor):
+    """The message for `tensors` in the form `communicator` carries: the arrays themselves, or one byte buffer."""
+    if carries_device_arrays(communicator):
+        ev = None
+        if tensors and tensors[0].is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(tensors[0].device))
+        STATS["device_arrays"] += len(tensors)
+        return DeviceArrays(tuple(t.detach() for t in tensors), ev)
+    return pack_many(*tensors)
+
+
+def incoming(message: Any, device: torch.device | str, expect: int) -> list[torch.Tensor]:
+    """The arrays of a received message (either form), on `device`; exactly `expect` of them."""
+    if isinstance(message, DeviceArrays):
+        if len(message.arrays) != expect:
+            raise ValueError(f"batch message carries {len(message.arrays)} arrays, expected {expect}")
+        dev = torch.device(device)
+        for t in message.arrays:
+            if not isinstance(t, torch.Tensor) or t.device != dev:
+                raise ValueError("device hand-over between different devices: use a byte transport")
+        if message.ready is not None:
+            torch.cuda.current_stream(dev).wait_event(message.ready)
+        return list(message.arrays)
+    return unpack_many(message, device, expect)
+
+
+def _as_view(buf: Any) -> memoryview:
+    try:
+        return memoryview(buf).cast("B")
+    except TypeError as exc:
+        raise ValueError("not a secure-comparison batch message") from exc
+
+
+def unpack_tensor(buf: Any, device: torch.device | str = "cpu") -> torch.Tensor:
     """Parse one array message.  The header comes from the peer: everything in it is checked against the bytes that
     actually arrived before an array of that shape is built (ValueError otherwise)."""
-    if len(buf) < 8 or buf[:4] != MAGIC:
+    t0 = time.perf_counter()
+    mv = _as_view(buf)
+    if len(mv) < 8 or bytes(mv[:4]) != MAGIC:
         raise ValueError("not a secure-comparison batch message")
-    code, ndim, _ = struct.unpack_from("<BBH", buf, 4)
+    code, ndim, _ = struct.unpack_from("<BBH", mv, 4)
     if code not in _DTYPES:
         raise ValueError(f"unknown dtype code {code} in batch message")
-    if ndim > MAX_NDIM or len(buf) < 8 + 8 * ndim:
+    if ndim > MAX_NDIM or len(mv) < 8 + 8 * ndim:
         raise ValueError("malformed batch message header")
-    shape = struct.unpack_from(f"<{ndim}Q", buf, 8)
+    shape = struct.unpack_from(f"<{ndim}Q", mv, 8)
     tdt, ndt = _DTYPES[code]
     count = 1
     for d in shape:
         count *= d
-    if count * ndt.itemsize != len(buf) - 8 - 8 * ndim:
-        raise ValueError(f"batch message announces shape {tuple(shape)} but carries {len(buf) - 8 - 8 * ndim} payload bytes")
-    arr = np.frombuffer(buf, dtype=ndt, offset=8 + 8 * ndim).reshape(shape)
-    return torch.from_numpy(arr.copy()).to(device)
+    if count * ndt.itemsize != len(mv) - 8 - 8 * ndim:
+        raise ValueError(f"batch message announces shape {tuple(shape)} but carries {len(mv) - 8 - 8 * ndim} payload bytes")
+    if count == 0:
+        out = torch.empty(tuple(shape), dtype=tdt, device=device)
+    else:
+        payload = mv[8 + 8 * ndim:]
+        import warnings
+
+        with warnings.catch_warnings():      # immutable `bytes` from a socket: wrapped all the same, and only ever read
+            warnings.filterwarnings("ignore", message=".*not writable.*")
+            host = torch.frombuffer(payload, dtype=torch.uint8).view(tdt).reshape(tuple(shape))   # wraps the received bytes in place
+        dev = torch.device(device)
+        out = host.to(dev) if dev.type != "cpu" else host.clone()
+    STATS["unpack_s"] += time.perf_counter() - t0
+    return out
 
 
 def expect_array(t: torch.Tensor, shape: tuple[int, ...], name: str, dtype: torch.dtype = torch.int32) -> torch.Tensor:
     """A received array must have exactly the dtype and shape this party's own parameters (l, B, key sizes) dictate: the
     kernels take sizes from the local side, never from the message."""
+    if not isinstance(t, torch.Tensor):
+        raise ValueError(f"{name}: received {type(t).__name__}, expected an array")
     if t.dtype != dtype:
         raise ValueError(f"{name}: received dtype {t.dtype}, expected {dtype}")
     if tuple(t.shape) != tuple(shape):
@@ -62,28 +178,24 @@ def expect_array(t: torch.Tensor, shape: tuple[int, ...], name: str, dtype: torc
     return t.contiguous()
 
 
-def pack_many(*tensors: torch.Tensor) -> bytes:
-    parts = [pack_tensor(t) for t in tensors]
-    return struct.pack("<I", len(parts)) + b"".join(struct.pack("<Q", len(p)) + p for p in parts)
-
-
-def unpack_many(buf: bytes, device: torch.device | str = "cpu", expect: int | None = None) -> list[torch.Tensor]:
-    if len(buf) < 4:
+def unpack_many(buf: Any, device: torch.device | str = "cpu", expect: int | None = None) -> list[torch.Tensor]:
+    mv = _as_view(buf)
+    if len(mv) < 4:
         raise ValueError("malformed batch message")
-    (n,) = struct.unpack_from("<I", buf, 0)
+    (n,) = struct.unpack_from("<I", mv, 0)
     if expect is not None and n != expect:
         raise ValueError(f"batch message carries {n} arrays, expected {expect}")
     if n > 64:
         raise ValueError("malformed batch message (array count)")
     off, out = 4, []
     for _ in range(n):
-        if off + 8 > len(buf):
+        if off + 8 > len(mv):
             raise ValueError("truncated batch message")
-        (ln,) = struct.unpack_from("<Q", buf, off)
+        (ln,) = struct.unpack_from("<Q", mv, off)
         off += 8
-        if off + ln > len(buf):
+        if off + ln > len(mv):
             raise ValueError("truncated batch message")
-        out.append(unpack_tensor(buf[off:off + ln], device))
+        out.append(unpack_tensor(mv[off:off + ln], device))
         off += ln
     return out
 
@@ -99,7 +211,7 @@ def pack_public_schemes(paillier, dgk) -> bytes:
 def unpack_public_schemes(buf: bytes, engine=None):
     from .schemes import DGK, Paillier
 
-    doc = json.loads(buf.decode())
+    doc = json.loads(bytes(buf).decode())
     d = doc["dgk"]
     return (Paillier(int(doc["paillier"]["n"], 16), engine=engine),
             DGK(int(d["n"], 16), int(d["g"], 16), int(d["h"], 16), int(d["u"], 16), d["t"], engine=engine,

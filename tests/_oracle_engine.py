@@ -32,6 +32,43 @@ class OracleEngine:
 
     def __init__(self):
         self._mods = {}
+        self._rng_key, self._rng_call = None, 0
+
+    # ---- the library's generator, restated (oracle/chacha_rng.py)
+    def rng_seed(self, key=None):
+        import os
+
+        self._rng_key, self._rng_call = (os.urandom(32) if key is None else bytes(key)), 0
+
+    def _rng_next_call(self):
+        if self._rng_key is None:
+            self.rng_seed()
+        self._rng_call += 1
+        return self._rng_call - 1
+
+    def rng_bits(self, bits, count):
+        from oracle import chacha_rng as c
+
+        return self.upload(c.rng_bits(self._rng_key, self._rng_next_call(), bits, count) if count else [], (bits + 31) // 32) \
+            if count else self.empty(0, (bits + 31) // 32)
+
+    def rng_below(self, n, count, nonzero=False):
+        from oracle import chacha_rng as c
+
+        call = self._rng_next_call()
+        return self.upload(c.rng_below(self._rng_key, call, n, count, nonzero), (n.bit_length() + 31) // 32)
+
+    def rng_coins(self, count):
+        from oracle import chacha_rng as c
+
+        call = self._rng_next_call()
+        return torch.tensor(c.rng_coins(self._rng_key, call, count), dtype=torch.int64)
+
+    def rng_permutations(self, k, count):
+        from oracle import chacha_rng as c
+
+        call = self._rng_next_call()
+        return torch.tensor(c.rng_permutations(self._rng_key, call, k, count), dtype=torch.int64).reshape(count, k)
 
     # ---- plumbing
     def upload(self, xs, nwords):

@@ -24,7 +24,7 @@ def test_library_builds_loads_and_exports_everything():
     for name in names:
         assert hasattr(lib, name), f"{name} declared in include/sc_amd.h but not exported"
     assert sorted(_lib.SYMBOLS) == names          # the ctypes binding covers the whole header
-    assert _lib.load().sc_abi_version() == 1
+    assert _lib.load().sc_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_no_gpu_means_loud_failure():

@@ -195,10 +195,14 @@ def test_batch_driver_layout_and_shuffle(world, use_crt):
     assert [osk.dec_raw(v) for v in eng.download(got)] == [int(x <= y) for x, y in zip(xs, ys)]
 
 
-def test_batched_interactive_protocol_and_wire_format(world):
-    """perform_secure_comparison_batch on both sides over the dictionary transport: (1) with injected draws it is
-    bit-identical to the oracle; (2) with OS randomness and device pools the decrypted results are right and the pools
-    are consumed exactly (1 + (l+1) per comparison for Alice, 3 + (l+1) for Bob)."""
+@pytest.mark.parametrize("device_tensors", [True, False])
+def test_batched_interactive_protocol_and_wire_format(world, device_tensors):
+    """perform_secure_comparison_batch on both sides over the dictionary transport, with the arrays handed over as they are
+    (device_tensors) and serialized into one byte buffer per message: (1) with injected draws it is bit-identical to the
+    oracle; (2) with draws=None every random input comes from the engine's generator (here: its CPU restatement) -- results
+    decrypt correctly, two runs differ, and the keyed stream makes a run reproducible."""
+    from protocols.secure_comparison_amd import wire
+
     osk, od, eng, bob_p, bob_d = world
     rng = random.Random(31)
     B = 5
@@ -210,10 +214,14 @@ def test_batched_interactive_protocol_and_wire_format(world):
     tx, ty = eng.upload(x_enc, 2 * nw), eng.upload(y_enc, 2 * nw)
     drs = [o.draw(rng, L, osk, od, 50) for _ in range(B)]
     draws = make_draws(eng, drs, L, nw, (od.u.bit_length() + 31) // 32, 2)
-    for use_draws in (True, False):
+    seen = []
+    for use_draws, key in ((True, None), (False, bytes(range(32))), (False, bytes(range(32))), (False, bytes(32))):
         box = {}
-        alice = Initiator(L, DictionaryCommunicator(box), "bob")
-        bob = KeyHolder(L, DictionaryCommunicator(box), "alice", bob_p, bob_d)
+        alice = Initiator(L, DictionaryCommunicator(box, device_tensors), "bob")
+        bob = KeyHolder(L, DictionaryCommunicator(box, device_tensors), "alice", bob_p, bob_d)
+        if key is not None:
+            eng.rng_seed(key)
+        wire.reset_stats()
 
         async def go():
             res, _ = await asyncio.gather(alice.perform_secure_comparison_batch(tx, ty, draws if use_draws else None, engine=eng),
@@ -227,9 +235,40 @@ def test_batched_interactive_protocol_and_wire_format(world):
         if use_draws:
             assert got == [o.compare(a, b, L, osk, od, d, True) for a, b, d in zip(x_enc, y_enc, drs)]
         else:
-            for scheme in (alice.scheme_paillier, alice.scheme_dgk, bob_p, bob_d):
-                assert scheme._batch_pool is not None and scheme._batch_pool.shape[0] == 0
+            seen.append(got)
+        assert (wire.STATS["device_arrays"] == 7 and wire.STATS["bytes"] == 0) if device_tensors else \
+            (wire.STATS["device_arrays"] == 0 and wire.STATS["bytes"] > B * (2 * (L + 1) * 4 * bob_d.mod_n.nwords))
         assert alice.scheme_paillier == bob_p and alice.scheme_dgk == bob_d and not box
+    assert seen[0] == seen[1] and seen[0] != seen[2]        # same key, same stream; another key, other ciphertexts
+
+
+def test_bad_permutation_is_refused_before_the_send(world):
+    """An injected row that is not a permutation is caught on Alice's side before [c_i] leaves (the scatter target is
+    zero-filled, never stale memory)."""
+    osk, od, eng, bob_p, bob_d = world
+    rng = random.Random(5)
+    B = 3
+    nw = bob_p.mod_n.nwords
+    x_enc = [osk.enc_raw(rng.randrange(1 << L)) for _ in range(B)]
+    drs = [o.draw(rng, L, osk, od, 50) for _ in range(B)]
+    draws = make_draws(eng, drs, L, nw, (od.u.bit_length() + 31) // 32, 2)
+    draws.permutation[1, 0] = draws.permutation[1, 1]
+    assert not bool(Initiator.permutation_is_valid(draws.permutation))
+    box = {}
+    alice = Initiator(L, DictionaryCommunicator(box), "bob")
+    bob = KeyHolder(L, DictionaryCommunicator(box), "alice", bob_p, bob_d)
+
+    async def go():
+        t = eng.upload(x_enc, 2 * nw)
+        b_task = asyncio.ensure_future(bob.perform_secure_comparison_batch(draws))
+        try:
+            await alice.perform_secure_comparison_batch(t, t, draws, engine=eng)
+        finally:
+            b_task.cancel()
+
+    with pytest.raises(ValueError, match="permutation"):
+        asyncio.run(go())
+    assert "step_4i_batch_session_1" not in box
 
 
 def test_wire_and_randomness_helpers():
@@ -239,17 +278,30 @@ def test_wire_and_randomness_helpers():
     import numpy as np
 
     n = (1 << 1023) + 99
-    t = R.uniform_below(n, 300, "cpu", nonzero=True)
-    vals = words_to_ints(t.numpy().view(np.uint32))
-    assert all(0 < v < n for v in vals) and len(set(vals)) == 300
-    bits = R.random_bits(35, (4, 7), "cpu")
-    assert bits.shape == (4, 7, 2) and int((bits[..., 1].to(torch.int64) & 0xFFFFFFFF).max()) < 8
-    perms = R.random_permutations(6, 17, "cpu")
-    assert all(sorted(p.tolist()) == list(range(17)) for p in perms)
+    eng = OracleEngine()
+    g = torch.Generator().manual_seed(5)
+    for source, gen in (("device", None), ("torch", g)):
+        t = R.uniform_below(n, 300, eng, source, gen, nonzero=True)
+        vals = words_to_ints(t.numpy().view(np.uint32))
+        assert all(0 < v < n for v in vals) and len(set(vals)) == 300
+        bits = R.random_bits(35, (4, 7), eng, source, gen)
+        assert bits.shape == (4, 7, 2) and int((bits[..., 1].to(torch.int64) & 0xFFFFFFFF).max()) < 8
+        perms = R.random_permutations(6, 17, eng, source, gen)
+        assert perms.dtype == torch.int64 and all(sorted(p.tolist()) == list(range(17)) for p in perms)
+        coins = R.random_coins(700, eng, source, gen)
+        assert coins.dtype == torch.int64 and set(coins.tolist()) == {0, 1}
+    with pytest.raises(ValueError):
+        R.uniform_below(n, 3, "cpu")        # the device source needs the engine whose generator draws
     a, b, c = wire.unpack_many(wire.pack_many(t, perms, torch.tensor([1, 0], dtype=torch.uint8)))
     assert torch.equal(a, t) and torch.equal(b, perms) and c.dtype == torch.uint8
+    assert torch.equal(wire.unpack_tensor(bytes(wire.pack_tensor(perms))), perms)      # immutable bytes from a socket
+    assert wire.unpack_tensor(wire.pack_tensor(torch.zeros((0, 4), dtype=torch.int32))).shape == (0, 4)
     with pytest.raises(ValueError):
         wire.unpack_tensor(b"nope" + bytes(16))
+    with pytest.raises(ValueError):
+        wire.incoming(wire.DeviceArrays((t,)), "cpu", expect=2)
+    with pytest.raises(ValueError):
+        wire.incoming(wire.DeviceArrays(("not an array",)), "cpu", expect=1)
 
 
 def test_freshness_discipline(world):

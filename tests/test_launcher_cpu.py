@@ -73,3 +73,56 @@ def test_bench_refuses_rank_counts_it_cannot_honour():
     cp = subprocess.run([sys.executable, bench, "--gpus", "8", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True,
                         timeout=300)
     assert cp.returncode != 0 and "WORLD_SIZE" in cp.stderr and "n_gpus" not in cp.stdout
+
+
+def test_gpu_count_comes_from_the_driver_files_not_from_hip(tmp_path, monkeypatch):
+    """The spawning parent counts GPUs from /sys/class/kfd-style topology files (CPU nodes have simd_count 0) and narrows the
+    count by the *_VISIBLE_DEVICES variables -- no HIP runtime is initialised for it."""
+    from protocols.secure_comparison_amd import launcher
+
+    for i, simd in enumerate([0, 0, 1024, 1024, 1024]):
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\nmem_banks_count 1\n")
+    for k in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(k, raising=False)
+    assert launcher.visible_gpus(str(tmp_path)) == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert launcher.visible_gpus(str(tmp_path)) == 2
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert launcher.visible_gpus(str(tmp_path)) == 0
+    assert launcher.host_threads_per_rank(1, 2) == min(2, os.cpu_count() or 1)
+    assert launcher.host_threads_per_rank(10 ** 6, 2) == 1
+
+
+def test_stuck_rank_is_killed_and_the_failure_is_named(tmp_path, monkeypatch, capfd):
+    """Rank 1 fails; rank 0 ignores SIGTERM (as a rank blocked in a collective does): the parent kills it after the grace period,
+    returns rank 1's exit code and prints that rank's last stderr lines."""
+    from protocols.secure_comparison_amd import launcher
+
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    script = tmp_path / "w.py"
+    script.write_text(
+        "import os, signal, sys, time\n"
+        "if os.environ['RANK'] == '1':\n"
+        "    time.sleep(0.5); sys.stderr.write('rank one says: boom\\n'); sys.exit(9)\n"
+        "signal.signal(signal.SIGTERM, signal.SIG_IGN)\n"
+        "time.sleep(120)\n")
+    import time
+
+    t0 = time.monotonic()
+    rc = launcher.spawn_ranks(str(script), [], 2, need_gpus=False, grace_s=1.0)
+    assert rc == 9 and time.monotonic() - t0 < 30
+    err = capfd.readouterr().err
+    assert "rank 1 exited with code 9" in err and "boom" in err
+
+
+def test_job_timeout(tmp_path, monkeypatch):
+    from protocols.secure_comparison_amd import launcher
+
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    script = tmp_path / "w.py"
+    script.write_text("import time\ntime.sleep(120)\n")
+    assert launcher.spawn_ranks(str(script), [], 2, need_gpus=False, timeout_s=1.0, grace_s=1.0) == 124

@@ -29,7 +29,7 @@ def world(keys):
 
 def test_wire_header_is_checked_against_the_payload():
     t = torch.arange(24, dtype=torch.int32).reshape(2, 3, 4)
-    buf = wire.pack_tensor(t)
+    buf = bytes(wire.pack_tensor(t))
     assert torch.equal(wire.unpack_tensor(buf), t)
     bad_dims = buf[:8] + struct.pack("<3Q", 2, 3, 400) + buf[32:]          # announces more items than it carries
     bad_code = buf[:4] + struct.pack("<BBH", 9, 3, 0) + buf[8:]            # unknown dtype code
@@ -37,7 +37,7 @@ def test_wire_header_is_checked_against_the_payload():
     for bad in (bad_dims, bad_code, bad_ndim, buf[:-4], buf[:6], b""):
         with pytest.raises(ValueError):
             wire.unpack_tensor(bad)
-    many = wire.pack_many(t, t)
+    many = bytes(wire.pack_many(t, t))
     assert len(wire.unpack_many(many, expect=2)) == 2
     for bad in (many[:-1], many[:10], struct.pack("<I", 3) + many[4:]):
         with pytest.raises(ValueError):
@@ -53,8 +53,8 @@ def test_wire_header_is_checked_against_the_payload():
 class _Tamper(DictionaryCommunicator):
     """Replaces the message with label `target` by `forge(original)` on its way to the receiver."""
 
-    def __init__(self, box, target, forge):
-        super().__init__(box)
+    def __init__(self, box, target, forge, device_tensors=False):
+        super().__init__(box, device_tensors)
         self.target, self.forge = target, forge
 
     async def recv(self, party_id, msg_id):
@@ -100,21 +100,41 @@ def _run_pair(world, alice_comm, bob_comm, B=3):
 def test_alice_refuses_malformed_batches(world, target, forge):
     box = {}
     with pytest.raises(ValueError):
-        _run_pair(world, _Tamper(box, target, forge), DictionaryCommunicator(box))
+        _run_pair(world, _Tamper(box, target, forge), DictionaryCommunicator(box, False))
 
 
 @pytest.mark.parametrize("target, forge", [
-    ("step_1_batch", lambda m: wire.pack_tensor(wire.unpack_tensor(m)[:, :-1].contiguous())),
-    ("step_1_batch", lambda m: wire.pack_tensor(wire.unpack_tensor(m).reshape(-1))),
-    ("step_1_batch", lambda m: wire.pack_tensor(wire.unpack_tensor(m).to(torch.uint8))),
-    ("step_4i_batch", lambda m: wire.pack_tensor(wire.unpack_tensor(m)[1:].contiguous())),                            # l planes instead of l + 1
-    ("step_4i_batch", lambda m: wire.pack_tensor(wire.unpack_tensor(m)[:, :-1].contiguous())),                        # B - 1 comparisons
-    ("step_4i_batch", lambda m: wire.pack_tensor(wire.unpack_tensor(m).to(torch.int64))),
+    ("step_1_batch", lambda m: wire.pack_many(wire.unpack_many(m)[0][:, :-1].contiguous())),
+    ("step_1_batch", lambda m: wire.pack_many(wire.unpack_many(m)[0].reshape(-1))),
+    ("step_1_batch", lambda m: wire.pack_many(wire.unpack_many(m)[0].to(torch.uint8))),
+    ("step_1_batch", lambda m: wire.pack_tensor(wire.unpack_many(m)[0])),                                              # unframed array
+    ("step_4i_batch", lambda m: wire.pack_many(wire.unpack_many(m)[0][1:].contiguous())),                             # l planes instead of l + 1
+    ("step_4i_batch", lambda m: wire.pack_many(wire.unpack_many(m)[0][:, :-1].contiguous())),                         # B - 1 comparisons
+    ("step_4i_batch", lambda m: wire.pack_many(wire.unpack_many(m)[0].to(torch.int64))),
+    ("step_4i_batch", lambda m: wire.pack_many(*wire.unpack_many(m), *wire.unpack_many(m))),                          # one array too many
 ])
 def test_bob_refuses_malformed_batches(world, target, forge):
     box = {}
     with pytest.raises(ValueError):
-        _run_pair(world, DictionaryCommunicator(box), _Tamper(box, target, forge))
+        _run_pair(world, DictionaryCommunicator(box, False), _Tamper(box, target, forge))
+
+
+@pytest.mark.parametrize("side, target, forge", [
+    # the device hand-over form (wire.DeviceArrays) is checked like bytes: array count, dtype, shape -- and that it is arrays at all
+    ("alice", "step_4b_batch", lambda m: wire.DeviceArrays((m.arrays[0],))),
+    ("alice", "step_4b_batch", lambda m: wire.DeviceArrays((m.arrays[0], m.arrays[1][:-1]))),
+    ("alice", "step_5_batch", lambda m: wire.DeviceArrays(tuple(t.to(torch.int64) for t in m.arrays))),
+    ("alice", "step_5_batch", lambda m: wire.DeviceArrays((m.arrays[0], m.arrays[1], "zeta"))),
+    ("bob", "step_1_batch", lambda m: wire.DeviceArrays((m.arrays[0][:, :-1],))),
+    ("bob", "step_1_batch", lambda m: wire.DeviceArrays((None,))),
+    ("bob", "step_4i_batch", lambda m: wire.DeviceArrays((m.arrays[0][:, :-1],))),
+    ("bob", "step_4i_batch", lambda m: b"SCB1" + bytes(40)),
+])
+def test_device_hand_over_is_checked_too(world, side, target, forge):
+    box = {}
+    tamper, plain = _Tamper(box, target, forge, device_tensors=True), DictionaryCommunicator(box, True)
+    with pytest.raises(ValueError):
+        _run_pair(world, *((tamper, plain) if side == "alice" else (plain, tamper)))
 
 
 def test_untampered_pair_still_runs(world):
