@@ -319,12 +319,13 @@ def main() -> None:
             if i > 0:
                 bob_d.share_tables_from(sets[0].bob_dgk)
                 alice_d.share_tables_from(sets[0].alice_dgk)
-            _ = alice_d.fb_h                      # untimed set-up, like key generation ("excluding table build")
-            _ = bob_d._crt_setup() if use_crt else bob_d.fb_h
+            alice_d.prepare(), bob_d.prepare()    # key objects + tables: untimed set-up, like key generation ("excluding table build")
+            alice_pai = bob_p.public_copy()
+            _ = bob_p.key, alice_pai.key          # Paillier key objects (moduli, exponents, CRT constants): set-up as well
             if i == 0:
                 build_s = alice_d.table_build_s + bob_d.table_build_s
                 table_bytes = alice_d.table_bytes() + bob_d.table_bytes()
-            sets.append(PartySet(bob_p.public_copy(), alice_d, bob_p, bob_d, torch.cuda.Stream()))
+            sets.append(PartySet(alice_pai, alice_d, bob_p, bob_d, torch.cuda.Stream()))
         return sets, build_s, table_bytes
 
     parties, table_build_s, table_bytes = build_parties(args.fb_window)

@@ -196,6 +196,88 @@ int sc_dgk_step4(sc_ctx* ctx, int mod, int cst_g, int cst_ginv, int l, const uin
                  const uint64_t* alpha_dptr, const uint64_t* alpha_tilde_dptr, const uint64_t* rsmall_dptr,
                  const uint64_t* delta_a_dptr, uint32_t* c_out_dptr, uint64_t count);
 
+/* ---- scheme-level entry points: what the reference's scheme objects and protocol steps do, one call each ------------- */
+/* A key object holds everything the scheme constructors derive ([ext] Paillier / DGK __init__; SC/keyholder.py:155-166): the
+ * moduli N, N^2 (and p, p^2, q, q^2 for the key holder), the exponents N, lambda, p-1, q mod (p-1) .., mu / h_p / the CRT
+ * recombination constants, g^-1, and the fixed-base tables for h.  With p / q (and v_p / v_q) the key is the key holder's and
+ * -- unless SC_KEY_NO_CRT -- every exponentiation runs through CRT (identical integers, ~3.3x fewer limb products); without
+ * them it is the public copy Alice receives (SC/initiator.py:177-203).  SC_KEY_NO_PAIRS forces exponentiations modulo N^2 to
+ * use products modulo N^2 instead of the pair arithmetic modulo N (measurement / tests).  All arrays of the calls below are
+ * device arrays of canonical words; N has `nwords` words, ciphertexts 2 * nwords; DGK residues `nwords` of its key. */
+#define SC_KEY_NO_CRT 1
+#define SC_KEY_NO_PAIRS 2
+int sc_paillier_key_create(sc_ctx* ctx, const uint32_t* n_hptr, int nwords, const uint32_t* p_hptr /* nullable */,
+                           const uint32_t* q_hptr /* nullable */, int pwords, int flags, int* out_key);
+/* the primitive handles behind a key (for callers that mix scheme-level and primitive calls) */
+int sc_paillier_key_mods(sc_ctx* ctx, int key, int* out_mod_n, int* out_mod_n2);
+/* out[i] = 1 + m[i] N (negate: 1 - m[i] N) mod N^2: unsafe_encrypt(m, apply_encoding=False), SC/initiator.py:256, 562;
+ * SC/keyholder.py:274-286. */
+int sc_paillier_encrypt(sc_ctx* ctx, int key, const uint32_t* m_dptr, int m_words, int negate, uint32_t* out_dptr, uint64_t count);
+/* ct.randomize() for a batch: out[i] = c[i] * rho[i]^N mod N^2 (c = NULL: the randomizers alone), rho: [count][nwords].
+ * SC/initiator.py:109; SC/keyholder.py:126-128 (the key holder's goes through CRT over p^2, q^2). */
+int sc_paillier_randomize(sc_ctx* ctx, int key, const uint32_t* c_dptr /* nullable */, const uint32_t* rho_dptr, uint32_t* out_dptr,
+                          uint64_t count);
+/* Paillier.decrypt(ct, apply_encoding=False): out[i] = L(c[i]^lambda mod N^2) mu mod N, [count][nwords] (SC/keyholder.py:195). */
+int sc_paillier_decrypt(sc_ctx* ctx, int key, const uint32_t* c_dptr, uint32_t* out_dptr, uint64_t count);
+/* DGK key: public (n, g, h, u, t) and optionally secret (p, q, v_p, v_q); randomizer_bits = width of the exponent r of h^r ([ext]
+ * ~2.5 t), window = fixed-base window of the tables for h (2^window rows per window).  table_src_ctx / table_src_key (nullable /
+ * ignored): another context of the same GPU whose key of the same modulus, h, window and width already built the tables -- they
+ * are shared read-only instead of built again (concurrent shard contexts; see sc_fbt_import). */
+int sc_dgk_key_create(sc_ctx* ctx, const uint32_t* n_hptr, const uint32_t* g_hptr, const uint32_t* h_hptr, int nwords,
+                      const uint32_t* u_hptr, int uwords, int t_bits, const uint32_t* p_hptr /* nullable */, const uint32_t* q_hptr,
+                      int pwords, const uint32_t* vp_hptr, const uint32_t* vq_hptr, int vwords, int randomizer_bits, int window,
+                      int flags, sc_ctx* table_src_ctx /* nullable */, int table_src_key, int* out_key);
+int sc_dgk_key_info(sc_ctx* ctx, int key, int* out_mod_n, int* out_mod_p /* -1 without secret key */, uint64_t* out_table_bytes);
+/* ct.randomize() for DGK: out[i] = c[i] * h^r[i] mod n (c = NULL: the randomizers alone); r: [count][ewords].
+ * SC/keyholder.py:106-108 (CRT with exponents reduced modulo v_p, v_q), SC/initiator.py:153-154. */
+int sc_dgk_randomize(sc_ctx* ctx, int key, const uint32_t* c_dptr /* nullable */, const uint32_t* r_dptr, int ewords,
+                     uint32_t* out_dptr, uint64_t count);
+/* unsafe_encrypt(bit) + .randomize() in one go: out[i] = g^bits[i] * h^r[i] mod n, bits: one byte per item
+ * (SC/keyholder.py:213, 231 with :106-108). */
+int sc_dgk_encrypt_bits_randomized(sc_ctx* ctx, int key, const uint8_t* bits_dptr, const uint32_t* r_dptr, int ewords,
+                                   uint32_t* out_dptr, uint64_t count);
+/* DGK.is_zero per ciphertext (SC/keyholder.py:249), and the whole of step 4j: any_flags[b] = OR over the planes of the bit-major
+ * vector c[planes][inner][nwords] (:246-253). */
+int sc_dgk_is_zero(sc_ctx* ctx, int key, const uint32_t* c_dptr, uint8_t* flags_dptr, uint64_t count);
+int sc_dgk_any_zero(sc_ctx* ctx, int key, const uint32_t* c_dptr, int planes, uint64_t inner, uint64_t* any_flags_dptr);
+
+/* Initiator.step_1 + step_3 + the plaintext side of 4c / 4e / 7 for a batch (SC/initiator.py:228-270, :289, :373, :558-562):
+ * z = [[y]] [[x]]^-1 [[2^l + r]] mod N^2, randomized with rho_z^N when rho_z is given (:109); alpha = r mod 2^l,
+ * alpha_tilde = (r - N) mod 2^l, rsmall = [r < (N-1)/2] (uint64 each), rshift = r div 2^l ([count][nwords]). */
+int sc_initiator_step1(sc_ctx* ctx, int paillier_key, int l, const uint32_t* x_enc_dptr, const uint32_t* y_enc_dptr,
+                       const uint32_t* r_dptr, const uint32_t* rho_z_dptr /* nullable */, uint32_t* z_out_dptr, uint64_t* alpha_dptr,
+                       uint64_t* alpha_tilde_dptr, uint64_t* rsmall_dptr, uint32_t* rshift_dptr, uint64_t count);
+/* KeyHolder.step_2 + step_4a + step_4b (+ the l + 1 .randomize() of SC/keyholder.py:106-108 when r_rand is given): decrypt z,
+ * derive beta / d / zeta_1 / zeta_2, and encrypt d and the bits of beta bit-major: d_beta_out[l+1][count][nwords(n)], plane 0 =
+ * [d], plane 1 + i = [beta_i].  z_out: [count][nwords(N)]; beta / dbit uint64. */
+int sc_keyholder_step2_4b(sc_ctx* ctx, int paillier_key, int dgk_key, int l, const uint32_t* z_enc_dptr,
+                          const uint32_t* r_rand_dptr /* nullable */, int r_words, uint32_t* z_out_dptr, uint64_t* beta_dptr,
+                          uint64_t* dbit_dptr, uint32_t* zeta1_dptr, uint32_t* zeta2_dptr, uint32_t* d_beta_out_dptr, uint64_t count);
+/* Initiator.step_4c .. step_4i for a batch (SC/initiator.py:272-516): one inversion pass over [d], [beta_i], the fused steps
+ * 4c-4h (sc_dgk_step4), then -- when rhos is given -- the blinding c_i^rho_i (:512), the re-randomization * h^r_i when r_rand is
+ * given (:153-154) and the shuffle when permutation ([count][l+1] int64, output k takes blinded c at index permutation[b][k]) is
+ * given (:516), the last three in ONE launch whose store is the shuffle.  beta: [l][count][nwords] bit-major; rhos / r_rand:
+ * [l+1][count][words].  c_unblinded_out (nullable) receives the output of step 4h.  c_out: [l+1][count][nwords]. */
+int sc_initiator_step4(sc_ctx* ctx, int dgk_key, int l, const uint32_t* d_enc_dptr, const uint32_t* beta_enc_dptr,
+                       const uint64_t* alpha_dptr, const uint64_t* alpha_tilde_dptr, const uint64_t* rsmall_dptr,
+                       const uint64_t* delta_a_dptr, const uint32_t* rhos_dptr /* nullable */, int rho_words,
+                       const int64_t* permutation_dptr /* nullable */, const uint32_t* r_rand_dptr /* nullable */, int r_words,
+                       uint32_t* c_unblinded_out_dptr /* nullable */, uint32_t* c_out_dptr, uint64_t count);
+/* Step 4i on its own (blinding, optional re-randomization, optional shuffle) for a vector c_in[l+1][count][nwords] that is already
+ * there (SC/initiator.py:487-516, :153-154); c_out must not be c_in when a permutation is given. */
+int sc_initiator_step4i(sc_ctx* ctx, int dgk_key, int l, const uint32_t* c_in_dptr, const uint32_t* rhos_dptr, int rho_words,
+                        const int64_t* permutation_dptr /* nullable */, const uint32_t* r_rand_dptr /* nullable */, int r_words,
+                        uint32_t* c_out_dptr, uint64_t count);
+/* KeyHolder.step_4j + step_5 (+ the 3 .randomize() of SC/keyholder.py:126-128 when rho3 is given): delta_B per comparison,
+ * then out3[3][count][2 nwords] = [[zeta_1]], [[zeta_2]], [[delta_B]]; rho3: [3][count][nwords] in the same order. */
+int sc_keyholder_step4j_5(sc_ctx* ctx, int paillier_key, int dgk_key, int l, const uint32_t* c_enc_dptr, const uint32_t* zeta1_dptr,
+                          const uint32_t* zeta2_dptr, const uint32_t* rho3_dptr /* nullable */, uint64_t* delta_b_out_dptr,
+                          uint32_t* out3_dptr, uint64_t count);
+/* Initiator.step_6 + step_7 (SC/initiator.py:518-564) with one inversion pass: out = [[x <= y]], not randomized. */
+int sc_initiator_step67(sc_ctx* ctx, int paillier_key, const uint64_t* delta_a_dptr, const uint32_t* delta_b_enc_dptr,
+                        const uint32_t* zeta1_enc_dptr, const uint32_t* zeta2_enc_dptr, const uint64_t* rsmall_dptr,
+                        const uint32_t* rshift_dptr, uint32_t* out_dptr, uint64_t count);
+
 /* ---- device-side CSPRNG: the random draws of a batch, generated where they are consumed ---------------- */
 /* The reference draws from Python's `secrets` (SC/initiator.py:223 permutation, :250 r, :420 delta_A, :512 rho_i) and the
  * scheme packages draw the randomizers behind every .randomize() ([ext]).  A batch of 65536 comparisons needs ~0.3 GB of such

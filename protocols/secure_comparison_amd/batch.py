@@ -94,24 +94,17 @@ def secure_comparison_batch(x_enc: torch.Tensor, y_enc: torch.Tensor, l: int, al
     False = the static step chain without randomization."""
     if randomize == "pool":
         return _secure_comparison_batch_pooled(x_enc, y_enc, l, alice_paillier, alice_dgk, bob_paillier, bob_dgk, draws)
-    # Alice: steps 1, 3
-    z_enc, a_plain = Initiator.step_1_batch(x_enc, y_enc, l, alice_paillier, draws.r)
-    if randomize:
-        z_enc = alice_paillier.randomize_batch(z_enc, draws.rho_z)
-    # Bob: steps 2, 4a, 4b
-    b_plain = KeyHolder.step_2_batch(z_enc, l, bob_paillier)
-    d_enc, beta_enc = KeyHolder.step_4a_4b_batch(b_plain, l, bob_dgk, bob_paillier, draws.r_bob_dgk if randomize else None)
-    # Alice: steps 4c-4i
-    c_h = Initiator.step_4c_to_4h_batch(d_enc, beta_enc, a_plain, draws.delta_a, alice_dgk)
-    c_sent = Initiator.step_4i_batch(c_h, alice_dgk, draws.rhos, draws.permutation, draws.r_alice_dgk if randomize else None)
-    # Bob: steps 4j, 5
-    delta_b = KeyHolder.step_4j_batch(c_sent, bob_dgk)
-    zeta_1_enc, zeta_2_enc, delta_b_enc = KeyHolder.step_5_batch(b_plain, delta_b, bob_paillier)
-    if randomize:
-        count = zeta_1_enc.shape[0]
-        rnd = bob_paillier.randomize_batch(cat_rows([zeta_1_enc, zeta_2_enc, delta_b_enc]),     # three blocks of one array: a view
-                                           cat_rows([draws.rho_zeta_1, draws.rho_zeta_2, draws.rho_delta_b]))
-        zeta_1_enc, zeta_2_enc, delta_b_enc = rnd[:count], rnd[count:2 * count], rnd[2 * count:]
+    # five library calls per batch (include/sc_amd.h, scheme-level entry points)
+    # Alice: steps 1, 3 (+ the randomization of [[z]])
+    z_enc, a_plain = Initiator.step_1_batch(x_enc, y_enc, l, alice_paillier, draws.r, draws.rho_z if randomize else None)
+    # Bob: steps 2, 4a, 4b (+ l + 1 randomizations)
+    b_plain, d_enc, beta_enc = KeyHolder.step_2_4b_batch(z_enc, l, bob_paillier, bob_dgk, draws.r_bob_dgk if randomize else None)
+    # Alice: steps 4c-4i (+ l + 1 randomizations, shuffle)
+    c_sent, c_h = Initiator.step_4_batch(d_enc, beta_enc, a_plain, draws.delta_a, alice_dgk, draws.rhos, draws.permutation,
+                                         draws.r_alice_dgk if randomize else None, want_unblinded=trace is not None)
+    # Bob: steps 4j, 5 (+ 3 randomizations)
+    rho3 = cat_rows([draws.rho_zeta_1, draws.rho_zeta_2, draws.rho_delta_b]) if randomize else None   # three blocks of one array: a view
+    delta_b, zeta_1_enc, zeta_2_enc, delta_b_enc = KeyHolder.step_4j_5_batch(c_sent, b_plain, bob_paillier, bob_dgk, rho3)
     # Alice: steps 6, 7
     result = Initiator.step_6_7_batch(draws.delta_a, delta_b_enc, zeta_1_enc, zeta_2_enc, a_plain, l, alice_paillier)
     if trace is not None:

@@ -181,11 +181,14 @@ struct sc_ctx {
   std::map<int, int> pair_twins;                            // mod -> context of the same modulus in a pair-capable configuration
   std::map<int, uint32_t*> pair_consts;                     // mod -> 4 limb arrays: pair(R^2), pair(B R) for the pair arithmetic
   RngKey rng_key;                                           // ChaCha20 key of the context's generator (sc_rng_seed)
+  void* scheme_keys = nullptr;                              // Paillier / DGK key objects of the scheme-level entry points (sc_schemes.h)
   bool rng_seeded = false;
   uint64_t rng_call = 0;                                    // generator calls since seeding: part of every keystream's nonce
 };
 
 namespace {
+
+void free_scheme_keys(void* p);   // sc_schemes.h
 
 int fail(sc_ctx* ctx, int code, const char* fmt, ...) {
   char buf[512];
@@ -556,6 +559,7 @@ void sc_ctx_destroy(sc_ctx* ctx) {
   for (auto& kv : ctx->tmp) if (kv.second.first) (void)hipFree(kv.second.first);
   if (ctx->switch_event) (void)hipEventDestroy(ctx->switch_event);
   if (ctx->comm) (void)sc_comm_destroy(ctx);
+  if (ctx->scheme_keys) free_scheme_keys(ctx->scheme_keys);
   delete ctx;
 }
 
@@ -1718,3 +1722,5 @@ int sc_mac_counter(sc_ctx* ctx, int reset, double* out_macs) {
 }
 
 }  // extern "C"
+
+#include "sc_schemes.h"

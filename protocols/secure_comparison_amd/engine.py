@@ -40,6 +40,29 @@ class FixedBase:
     window: int
 
 
+@dataclass(frozen=True)
+class PaillierKey:
+    """Handle of a library-side Paillier key object (sc_paillier_key_create)."""
+
+    id: int
+    mod_n: Modulus
+    mod_n2: Modulus
+    secret: bool
+
+
+@dataclass(frozen=True)
+class DgkKey:
+    """Handle of a library-side DGK key object (sc_dgk_key_create)."""
+
+    id: int
+    mod_n: Modulus
+    mod_p: Modulus | None
+    u: int
+    randomizer_bits: int
+    window: int
+    secret: bool
+
+
 class Engine:
     """One context per process/device.  Tensors are int32 views of uint32 words, shape [count, nwords]."""
 
@@ -455,6 +478,242 @@ class Engine:
     def comm_destroy(self) -> None:
         self._check(self.lib.sc_comm_destroy(self.ctx))
         self._comm_nranks = 0
+
+    # ------------------------------------------------------------------ scheme-level entry points (one library call each)
+    def _words_arg(self, x: int | None, nwords: int):
+        if x is None:
+            return None, C.c_void_p(0)
+        return self._host_words(x, nwords)
+
+    def _mod_handle(self, mid: int, n: int, nwords: int) -> Modulus:
+        return self._mods.setdefault((n, nwords), Modulus(mid, n, nwords))
+
+    def paillier_key(self, n: int, p: int | None = None, q: int | None = None, use_crt: bool = True, use_pairs: bool = True) -> PaillierKey:
+        """Library-side key object: every modulus / exponent / constant the scheme derives, the key holder's CRT included."""
+        nw = (n.bit_length() + 31) // 32
+        pw = 0 if p is None else (max(p.bit_length(), q.bit_length()) + 31) // 32
+        a_n, p_n = self._host_words(n, nw)
+        a_p, p_p = self._words_arg(p, pw)
+        a_q, p_q = self._words_arg(q, pw)
+        kid, m1, m2 = C.c_int(), C.c_int(), C.c_int()
+        self._sync_stream()
+        self._check(self.lib.sc_paillier_key_create(self.ctx, p_n, nw, p_p, p_q, pw, (0 if use_crt else 1) | (0 if use_pairs else 2), C.byref(kid)))
+        self._check(self.lib.sc_paillier_key_mods(self.ctx, kid.value, C.byref(m1), C.byref(m2)))
+        return PaillierKey(kid.value, self._mod_handle(m1.value, n, nw), self._mod_handle(m2.value, n * n, 2 * nw), p is not None)
+
+    def paillier_encrypt(self, key: PaillierKey, m: torch.Tensor, negate: bool = False, out: torch.Tensor | None = None) -> torch.Tensor:
+        count = self._items(m)
+        self._arr(m, "m", count)
+        out = self._out(out, count, key.mod_n2.nwords)
+        self._sync_stream()
+        self._check(self.lib.sc_paillier_encrypt(self.ctx, key.id, self._ptr(m), m.shape[-1], int(negate), self._ptr(out), count))
+        return out
+
+    def paillier_randomize(self, key: PaillierKey, c: torch.Tensor | None, rho: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        """c * rho^N mod N^2 (c None: the randomizers): ct.randomize() for a batch."""
+        count = self._items(rho)
+        self._arr(rho, "rho", count, key.mod_n.nwords)
+        self._arr(c, "c", count, key.mod_n2.nwords, optional=True)
+        out = self._out(out, count, key.mod_n2.nwords)
+        self._sync_stream()
+        self._check(self.lib.sc_paillier_randomize(self.ctx, key.id, self._ptr(c), self._ptr(rho), self._ptr(out), count))
+        return out
+
+    def paillier_decrypt(self, key: PaillierKey, c: torch.Tensor) -> torch.Tensor:
+        count = self._items(c)
+        self._arr(c, "c", count, key.mod_n2.nwords)
+        out = self.empty(count, key.mod_n.nwords)
+        self._sync_stream()
+        self._check(self.lib.sc_paillier_decrypt(self.ctx, key.id, self._ptr(c), self._ptr(out), count))
+        return out
+
+    def dgk_key(self, n: int, g: int, h: int, u: int, t: int, p: int | None = None, q: int | None = None, v_p: int | None = None,
+                v_q: int | None = None, randomizer_bits: int = 400, window: int = 8, use_crt: bool = True,
+                table_source: "tuple[Engine, DgkKey] | None" = None) -> DgkKey:
+        """Library-side DGK key object; builds the fixed-base tables for h (or takes `table_source`'s over, read-only)."""
+        nw, uw = (n.bit_length() + 31) // 32, (u.bit_length() + 31) // 32
+        pw = 0 if p is None else (max(p.bit_length(), q.bit_length()) + 31) // 32
+        vw = 0 if v_p is None else (max(v_p.bit_length(), v_q.bit_length()) + 31) // 32
+        keep = [self._host_words(x, nw) for x in (n, g % n, h % n)] + [self._host_words(u, uw)]
+        sec = [self._words_arg(x, w) for x, w in ((p, pw), (q, pw), (v_p, vw), (v_q, vw))]
+        if table_source is not None and table_source[0] is self:
+            return table_source[1]
+        src_ctx, src_key = (C.c_void_p(0), -1) if table_source is None else (table_source[0].ctx, table_source[1].id)
+        kid, m_n, m_p = C.c_int(), C.c_int(), C.c_int()
+        self._sync_stream()
+        self._check(self.lib.sc_dgk_key_create(self.ctx, keep[0][1], keep[1][1], keep[2][1], nw, keep[3][1], uw, int(t), sec[0][1], sec[1][1], pw,
+                                               sec[2][1], sec[3][1], vw, int(randomizer_bits), int(window), 0 if use_crt else 1, src_ctx, src_key,
+                                               C.byref(kid)))
+        self._check(self.lib.sc_dgk_key_info(self.ctx, kid.value, C.byref(m_n), C.byref(m_p), None))
+        mod_p = None if p is None else self._mod_handle(m_p.value, p, (p.bit_length() + 31) // 32)
+        return DgkKey(kid.value, self._mod_handle(m_n.value, n, nw), mod_p, u, int(randomizer_bits), int(window), p is not None)
+
+    def dgk_table_bytes(self, key: DgkKey) -> int:
+        v = C.c_uint64()
+        self._check(self.lib.sc_dgk_key_info(self.ctx, key.id, None, None, C.byref(v)))
+        return int(v.value)
+
+    def dgk_randomize(self, key: DgkKey, c: torch.Tensor | None, r: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        """c * h^r mod n (c None: the randomizers)."""
+        count = self._items(r)
+        self._arr(r, "r", count)
+        self._arr(c, "c", count, key.mod_n.nwords, optional=True)
+        out = self._out(out, count, key.mod_n.nwords)
+        self._sync_stream()
+        self._check(self.lib.sc_dgk_randomize(self.ctx, key.id, self._ptr(c), self._ptr(r), r.shape[-1], self._ptr(out), count))
+        return out
+
+    def dgk_encrypt_bits_randomized(self, key: DgkKey, bits: torch.Tensor, r: torch.Tensor) -> torch.Tensor:
+        """g^bits[i] * h^r[i] mod n; bits: uint8 [count]."""
+        count = self._items(r)
+        self._arr(r, "r", count)
+        self._arr(bits, "bits", dtype=torch.uint8)
+        if bits.numel() != count:
+            raise ValueError(f"bits: {bits.numel()} items, expected {count}")
+        out = self.empty(count, key.mod_n.nwords)
+        self._sync_stream()
+        self._check(self.lib.sc_dgk_encrypt_bits_randomized(self.ctx, key.id, self._ptr(bits), self._ptr(r), r.shape[-1], self._ptr(out), count))
+        return out
+
+    def dgk_is_zero(self, key: DgkKey, c: torch.Tensor) -> torch.Tensor:
+        count = self._items(c)
+        self._arr(c, "c", count, key.mod_n.nwords)
+        flags = torch.empty((count,), dtype=torch.uint8, device=self.device)
+        self._sync_stream()
+        self._check(self.lib.sc_dgk_is_zero(self.ctx, key.id, self._ptr(c), self._ptr(flags), count))
+        return flags
+
+    def dgk_any_zero(self, key: DgkKey, c: torch.Tensor) -> torch.Tensor:
+        """int64 [B]: 1 where some plane of c [planes][B][nw] decrypts to zero (KeyHolder.step_4j)."""
+        self._arr(c, "c", words=key.mod_n.nwords)
+        if c.dim() != 3:
+            raise ValueError("c: expected [planes][B][nwords]")
+        planes, inner, _ = c.shape
+        out = torch.empty((inner,), dtype=torch.int64, device=self.device)
+        self._sync_stream()
+        self._check(self.lib.sc_dgk_any_zero(self.ctx, key.id, self._ptr(c), planes, inner, self._ptr(out)))
+        return out
+
+    def _flags(self, count: int, **arrays: torch.Tensor) -> None:
+        for name, t in arrays.items():
+            self._arr(t, name, dtype=torch.int64)
+            if t.numel() != count:
+                raise ValueError(f"{name}: {t.numel()} items, expected {count}")
+
+    def initiator_step1(self, key: PaillierKey, l: int, x_enc: torch.Tensor, y_enc: torch.Tensor, r: torch.Tensor,
+                        rho_z: torch.Tensor | None = None):
+        """(z_enc, alpha, alpha_tilde, r_small, r_shift): Initiator.step_1 / step_3 for a batch, [[z]] randomized with rho_z^N."""
+        count = self._items(x_enc)
+        nw = key.mod_n.nwords
+        self._arr(x_enc, "x_enc", count, 2 * nw)
+        self._arr(y_enc, "y_enc", count, 2 * nw)
+        self._arr(r, "r", count, nw)
+        self._arr(rho_z, "rho_z", count, nw, optional=True)
+        z = self.empty(count, 2 * nw)
+        alpha = torch.empty((count,), dtype=torch.int64, device=self.device)
+        alpha_t, rsmall = torch.empty_like(alpha), torch.empty_like(alpha)
+        rshift = self.empty(count, nw)
+        self._sync_stream()
+        rc = self.lib.sc_initiator_step1(self.ctx, key.id, int(l), self._ptr(x_enc), self._ptr(y_enc), self._ptr(r), self._ptr(rho_z), self._ptr(z),
+                                         self._ptr(alpha), self._ptr(alpha_t), self._ptr(rsmall), self._ptr(rshift), count)
+        self._check(rc)
+        return z, alpha, alpha_t, rsmall, rshift
+
+    def keyholder_step2_4b(self, pkey: PaillierKey, dkey: DgkKey, l: int, z_enc: torch.Tensor, r_rand: torch.Tensor | None = None):
+        """(z, beta, d, zeta_1, zeta_2, [d],[beta_i] as [l+1][B][nw]): KeyHolder.step_2 / 4a / 4b (+ their randomizations)."""
+        count = self._items(z_enc)
+        nw, nd = pkey.mod_n.nwords, dkey.mod_n.nwords
+        self._arr(z_enc, "z_enc", count, 2 * nw)
+        self._arr(r_rand, "r_rand", (l + 1) * count, optional=True)
+        z, zeta1, zeta2 = self.empty(count, nw), self.empty(count, nw), self.empty(count, nw)
+        beta = torch.empty((count,), dtype=torch.int64, device=self.device)
+        dbit = torch.empty_like(beta)
+        out = torch.empty((l + 1, count, nd), dtype=torch.int32, device=self.device)
+        self._sync_stream()
+        self._check(self.lib.sc_keyholder_step2_4b(self.ctx, pkey.id, dkey.id, int(l), self._ptr(z_enc), self._ptr(r_rand),
+                                                   0 if r_rand is None else r_rand.shape[-1], self._ptr(z), self._ptr(beta), self._ptr(dbit),
+                                                   self._ptr(zeta1), self._ptr(zeta2), self._ptr(out), count))
+        return z, beta, dbit, zeta1, zeta2, out
+
+    def initiator_step4(self, key: DgkKey, l: int, d_enc: torch.Tensor, beta_enc: torch.Tensor, alpha: torch.Tensor, alpha_tilde: torch.Tensor,
+                        rsmall: torch.Tensor, delta_a: torch.Tensor, rhos: torch.Tensor | None = None, permutation: torch.Tensor | None = None,
+                        r_rand: torch.Tensor | None = None, want_unblinded: bool = False):
+        """(c, c after step 4h or None): Initiator.step_4c .. 4i for a batch; see sc_initiator_step4."""
+        count = self._items(d_enc)
+        nw = key.mod_n.nwords
+        self._arr(d_enc, "d_enc", count, nw)
+        self._arr(beta_enc, "beta_enc", l * count, nw)
+        self._flags(count, alpha=alpha, alpha_tilde=alpha_tilde, rsmall=rsmall, delta_a=delta_a)
+        self._arr(rhos, "rhos", (l + 1) * count, optional=True)
+        self._arr(r_rand, "r_rand", (l + 1) * count, optional=True)
+        if permutation is not None:
+            self._arr(permutation, "permutation", dtype=torch.int64)
+            if tuple(permutation.shape) != (count, l + 1):
+                raise ValueError(f"permutation: expected int64 [{count}][{l + 1}], got {tuple(permutation.shape)}")
+        out = torch.empty((l + 1, count, nw), dtype=torch.int32, device=self.device)
+        mid = torch.empty_like(out) if (want_unblinded and rhos is not None) else None
+        self._sync_stream()
+        rc = self.lib.sc_initiator_step4(self.ctx, key.id, int(l), self._ptr(d_enc), self._ptr(beta_enc), self._ptr(alpha), self._ptr(alpha_tilde),
+                                         self._ptr(rsmall), self._ptr(delta_a), self._ptr(rhos), 0 if rhos is None else rhos.shape[-1],
+                                         self._ptr(permutation), self._ptr(r_rand), 0 if r_rand is None else r_rand.shape[-1], self._ptr(mid),
+                                         self._ptr(out), count)
+        if rc == -3:
+            raise NotInvertibleError(self.lib.sc_last_error(self.ctx).decode())
+        self._check(rc)
+        return out, mid
+
+    def initiator_step4i(self, key: DgkKey, l: int, c_in: torch.Tensor, rhos: torch.Tensor, permutation: torch.Tensor | None = None,
+                         r_rand: torch.Tensor | None = None) -> torch.Tensor:
+        """Blinding c_i^rho_i [* h^r_i] and the per-comparison shuffle of a vector [l+1][B][nw] that is already there."""
+        nw = key.mod_n.nwords
+        if c_in.dim() != 3 or c_in.shape[0] != l + 1:
+            raise ValueError(f"c: expected [{l + 1}][B][{nw}], got {tuple(c_in.shape)}")
+        count = c_in.shape[1]
+        self._arr(c_in, "c", (l + 1) * count, nw)
+        self._arr(rhos, "rhos", (l + 1) * count)
+        self._arr(r_rand, "r_rand", (l + 1) * count, optional=True)
+        if permutation is not None:
+            self._arr(permutation, "permutation", dtype=torch.int64)
+            if tuple(permutation.shape) != (count, l + 1):
+                raise ValueError(f"permutation: expected int64 [{count}][{l + 1}], got {permutation.dtype} {tuple(permutation.shape)}")
+        out = torch.empty_like(c_in)
+        self._sync_stream()
+        self._check(self.lib.sc_initiator_step4i(self.ctx, key.id, int(l), self._ptr(c_in), self._ptr(rhos), rhos.shape[-1], self._ptr(permutation),
+                                                 self._ptr(r_rand), 0 if r_rand is None else r_rand.shape[-1], self._ptr(out), count))
+        return out
+
+    def keyholder_step4j_5(self, pkey: PaillierKey, dkey: DgkKey, l: int, c_enc: torch.Tensor, zeta1: torch.Tensor, zeta2: torch.Tensor,
+                           rho3: torch.Tensor | None = None):
+        """(delta_B int64 [B], [[zeta_1]] | [[zeta_2]] | [[delta_B]] as [3B][2nw]): KeyHolder.step_4j / step_5 (+ randomizations)."""
+        nw, nd = pkey.mod_n.nwords, dkey.mod_n.nwords
+        count = self._items(zeta1)
+        self._arr(c_enc, "c_enc", (l + 1) * count, nd)
+        self._arr(zeta1, "zeta_1", count, nw)
+        self._arr(zeta2, "zeta_2", count, nw)
+        self._arr(rho3, "rho3", 3 * count, nw, optional=True)
+        delta_b = torch.empty((count,), dtype=torch.int64, device=self.device)
+        out = self.empty(3 * count, 2 * nw)
+        self._sync_stream()
+        self._check(self.lib.sc_keyholder_step4j_5(self.ctx, pkey.id, dkey.id, int(l), self._ptr(c_enc), self._ptr(zeta1), self._ptr(zeta2),
+                                                   self._ptr(rho3), self._ptr(delta_b), self._ptr(out), count))
+        return delta_b, out
+
+    def initiator_step67(self, key: PaillierKey, delta_a: torch.Tensor, delta_b_enc: torch.Tensor, zeta1_enc: torch.Tensor, zeta2_enc: torch.Tensor,
+                         rsmall: torch.Tensor, rshift: torch.Tensor) -> torch.Tensor:
+        count = self._items(delta_b_enc)
+        nw = key.mod_n.nwords
+        for name, t in (("delta_b_enc", delta_b_enc), ("zeta_1_enc", zeta1_enc), ("zeta_2_enc", zeta2_enc)):
+            self._arr(t, name, count, 2 * nw)
+        self._arr(rshift, "r_shift", count, nw)
+        self._flags(count, delta_a=delta_a, rsmall=rsmall)
+        out = self.empty(count, 2 * nw)
+        self._sync_stream()
+        rc = self.lib.sc_initiator_step67(self.ctx, key.id, self._ptr(delta_a), self._ptr(delta_b_enc), self._ptr(zeta1_enc), self._ptr(zeta2_enc),
+                                          self._ptr(rsmall), self._ptr(rshift), self._ptr(out), count)
+        if rc == -3:
+            raise NotInvertibleError(self.lib.sc_last_error(self.ctx).decode())
+        self._check(rc)
+        return out
 
     # ------------------------------------------------------------------ device-side CSPRNG (sc_rng_*)
     def rng_seed(self, key: bytes | None = None) -> None:

@@ -27,7 +27,6 @@ class AlicePlain:
     """Plaintext-side values Alice derives from her blinding value r (one entry per comparison)."""
 
     r: torch.Tensor            # [B][nw]   r, 0 <= r < N                       (SC/initiator.py:250)
-    m1: torch.Tensor           # [B][nw+1] 2^l + r                            (:256)
     alpha: torch.Tensor        # [B] u64   r mod 2^l                           (:270)
     alpha_tilde: torch.Tensor  # [B] u64   (r - N) mod 2^l                     (:373)
     r_small: torch.Tensor      # [B] u64   [r < (N-1)//2]                      (:289, :559)
@@ -123,14 +122,12 @@ class Initiator:
         wire.expect_array(y_enc, (count, 2 * nw_p), "y_enc")
         if draws is None:
             draws = draw_alice(count, l, pai, dgk, source, generator)
-        z_enc, plain = Initiator.step_1_batch(x_enc, y_enc, l, pai, draws.r)
-        z_enc = pai.randomize_batch(z_enc, draws.rho_z)
+        z_enc, plain = Initiator.step_1_batch(x_enc, y_enc, l, pai, draws.r, draws.rho_z)
         await comm.send(self.other_party, wire.outgoing(comm, z_enc), msg_id=f"step_1_batch_session_{sid}")
         d_enc, beta_enc = wire.incoming(await comm.recv(self.other_party, msg_id=f"step_4b_batch_session_{sid}"), dev, expect=2)
         d_enc = wire.expect_array(d_enc, (count, nw_d), "[d]")                      # sizes come from this side's l and B,
         beta_enc = wire.expect_array(beta_enc, (l, count, nw_d), "[beta_i]")        # never from the message
-        c_h = Initiator.step_4c_to_4h_batch(d_enc, beta_enc, plain, draws.delta_a, dgk)
-        c = Initiator.step_4i_batch(c_h, dgk, draws.rhos, draws.permutation, draws.r_alice_dgk)
+        c, _ = Initiator.step_4_batch(d_enc, beta_enc, plain, draws.delta_a, dgk, draws.rhos, draws.permutation, draws.r_alice_dgk)
         if draws.permutation is not None and not bool(Initiator.permutation_is_valid(draws.permutation)):
             raise ValueError("permutation: a row is not a permutation of the l + 1 positions")   # before anything is sent
         await comm.send(self.other_party, wire.outgoing(comm, c), msg_id=f"step_4i_batch_session_{sid}")
@@ -256,63 +253,49 @@ class Initiator:
         zeta_enc = zeta_1_enc if r < (scheme_paillier.public_key.n - 1) // 2 else zeta_2_enc
         return zeta_enc - (scheme_paillier.unsafe_encrypt(r >> l, apply_encoding=False) + beta_lt_alpha_enc)
 
-    # ------------------------------------------------------------------ batched steps (device arrays)
+    # ------------------------------------------------------------------ batched steps (device arrays): one library call each
     @staticmethod
-    def step_1_batch(x_enc: torch.Tensor, y_enc: torch.Tensor, l: int, scheme_paillier: Paillier,
-                     r: torch.Tensor) -> tuple[torch.Tensor, AlicePlain]:
-        """B times step 1 + step 3 + the plaintext side of 4c/4e/7.  x_enc, y_enc: [B][2nw]; r: [B][nw] (injected)."""
+    def step_1_batch(x_enc: torch.Tensor, y_enc: torch.Tensor, l: int, scheme_paillier: Paillier, r: torch.Tensor,
+                     rho_z: torch.Tensor | None = None) -> tuple[torch.Tensor, AlicePlain]:
+        """B times step 1 + step 3 + the plaintext side of 4c/4e/7 (sc_initiator_step1).  x_enc, y_enc: [B][2nw]; r: [B][nw]
+        (injected); rho_z: [B][nw] = the `.randomize()` of [[z]] (SC/initiator.py:109) fused in."""
         n = scheme_paillier.public_key.n
         assert (1 << (l + 2)) < n // 2
-        e = scheme_paillier.engine
-        m1, alpha, alpha_tilde, r_small, r_shift = e.plain_alice(r, n, l)
-        z = scheme_paillier.add_batch(scheme_paillier.add_batch(y_enc, scheme_paillier.neg_batch(x_enc)),
-                                      scheme_paillier.encrypt_raw_batch(m1))
-        return z, AlicePlain(r, m1, alpha, alpha_tilde, r_small, r_shift)
+        z, alpha, alpha_tilde, r_small, r_shift = scheme_paillier.engine.initiator_step1(scheme_paillier.key, l, x_enc, y_enc, r, rho_z)
+        return z, AlicePlain(r, alpha, alpha_tilde, r_small, r_shift)
+
+    @staticmethod
+    def step_4_batch(d_enc: torch.Tensor, beta_is_enc: torch.Tensor, plain: AlicePlain, delta_a: torch.Tensor, scheme_dgk: DGK,
+                     rhos: torch.Tensor, permutation: torch.Tensor | None = None, randomizer_exponents: torch.Tensor | None = None,
+                     want_unblinded: bool = False) -> tuple[torch.Tensor, torch.Tensor | None]:
+        """Steps 4c .. 4i for B comparisons in ONE library call (sc_initiator_step4): the inversion pass over [d], [beta_i], the
+        fused steps 4c-4h, the blinding c_i^rho_i, the re-randomization * h^r_i (`randomizer_exponents`) and the shuffle.
+        Returns ([c_i] as sent: [l+1][B][nw], and the unblinded vector of step 4h when `want_unblinded`)."""
+        l = beta_is_enc.shape[0]
+        return scheme_dgk.engine.initiator_step4(scheme_dgk.key, l, d_enc, beta_is_enc, plain.alpha, plain.alpha_tilde, plain.r_small, delta_a,
+                                                 rhos, permutation, randomizer_exponents, want_unblinded)
 
     @staticmethod
     def step_4c_to_4h_batch(d_enc: torch.Tensor, beta_is_enc: torch.Tensor, plain: AlicePlain, delta_a: torch.Tensor,
                             scheme_dgk: DGK) -> torch.Tensor:
         """Steps 4c, 4d, 4e, 4f, 4h fused for B comparisons.  beta_is_enc: [l][B][nw] bit-major; d_enc: [B][nw];
         delta_a: [B] u64 (step 4g's draw, injected).  Returns [l+1][B][nw] = c_-1, c_0, .., c_{l-1} (not blinded)."""
-        from ._views import cat_rows
-
-        e = scheme_dgk.engine
-        l, count, nw = beta_is_enc.shape
-        # one inversion pass over [d], [beta_0] .. [beta_{l-1}]: a view when they arrive as the planes of one array (the
-        # batch driver's case), a copy when they came as two messages
-        planes = cat_rows([d_enc.reshape(1, count, nw), beta_is_enc])
-        inv = scheme_dgk.neg_batch(planes.reshape((l + 1) * count, nw))
-        d_inv, beta_inv = inv[:count], inv[count:].reshape(l, count, nw)
-        pk = scheme_dgk.public_key
-        return e.dgk_step4(scheme_dgk.mod_n, pk.g, scheme_dgk.g_inv, l, beta_is_enc, beta_inv, d_enc, d_inv, plain.alpha,
-                           plain.alpha_tilde, plain.r_small, delta_a)
+        l = beta_is_enc.shape[0]
+        return scheme_dgk.engine.initiator_step4(scheme_dgk.key, l, d_enc, beta_is_enc, plain.alpha, plain.alpha_tilde, plain.r_small, delta_a)[0]
 
     @staticmethod
     def step_4i_batch(c_is_enc: torch.Tensor, scheme_dgk: DGK, rhos: torch.Tensor, permutation: torch.Tensor | None = None,
                       randomizer_exponents: torch.Tensor | None = None) -> torch.Tensor:
         """Blinding c_i^rho_i (and, when `randomizer_exponents` is given, the `.randomize()` of SC/initiator.py:153-154
-        fused in: * h^r_i), then the per-comparison shuffle.  c_is_enc: [l+1][B][nw]; rhos: [l+1][B][ew];
-        permutation: [B][l+1] int64 (output k of comparison b takes blinded c at index permutation[b][k])."""
-        e = scheme_dgk.engine
+        fused in: * h^r_i), then the per-comparison shuffle -- in the store of the same launch (sc_initiator_step4i).
+        c_is_enc: [l+1][B][nw]; rhos: [l+1][B][ew]; permutation: [B][l+1] int64 (output k of comparison b takes blinded c at index
+        permutation[b][k]).  Entries are clamped into range inside the library and CHECKED lazily (permutation_is_valid: a device
+        flag the caller reads where it synchronises anyway); the scatter target is zero-filled, so a row that is not a permutation
+        leaves zero planes in that comparison's own vector, never stale device memory."""
         lp1, count, nw = c_is_enc.shape
-        ubits = (scheme_dgk.public_key.u - 1).bit_length()
-        dest, out = None, None
-        if permutation is not None:
-            # the shuffle rides in the store of the blinding launch: blinded plane j of comparison b goes to output plane
-            # k with permutation[b][k] == j, i.e. to flat row inverse[b][j] * B + b
-            if tuple(permutation.shape) != (count, lp1) or permutation.dtype != torch.int64:
-                raise ValueError(f"permutation: expected int64 [{count}][{lp1}], got {permutation.dtype} {tuple(permutation.shape)}")
-            # entries are clamped into range here and CHECKED lazily (permutation_is_valid: a device flag the caller reads where it
-            # synchronises anyway -- before the send in the interactive protocol); the scatter target is zero-filled, so a row that
-            # is not a permutation leaves zero planes in that comparison's own vector, never stale device memory
-            planes = torch.arange(lp1, device=permutation.device, dtype=torch.int64).expand(count, lp1)
-            inverse = torch.zeros_like(permutation).scatter_(1, permutation.clamp(0, lp1 - 1), planes)
-            dest = (inverse.t() * count + torch.arange(count, device=permutation.device, dtype=torch.int64)).reshape(-1).contiguous()
-            out = torch.zeros((lp1 * count, nw), dtype=torch.int32, device=c_is_enc.device)
-        flat = e.modexp_var(scheme_dgk.mod_n, c_is_enc.reshape(lp1 * count, nw), rhos.reshape(lp1 * count, -1), ubits,
-                            scheme_dgk.fb_h if randomizer_exponents is not None else None,
-                            None if randomizer_exponents is None else randomizer_exponents.reshape(lp1 * count, -1), dest=dest, out=out)
-        return flat.reshape(lp1, count, nw)
+        if permutation is not None and (tuple(permutation.shape) != (count, lp1) or permutation.dtype != torch.int64):
+            raise ValueError(f"permutation: expected int64 [{count}][{lp1}], got {permutation.dtype} {tuple(permutation.shape)}")
+        return scheme_dgk.engine.initiator_step4i(scheme_dgk.key, lp1 - 1, c_is_enc, rhos, permutation, randomizer_exponents)
 
     @staticmethod
     def permutation_is_valid(permutation: torch.Tensor) -> torch.Tensor:
@@ -340,17 +323,10 @@ class Initiator:
     @staticmethod
     def step_6_7_batch(delta_a: torch.Tensor, delta_b_enc: torch.Tensor, zeta_1_enc: torch.Tensor, zeta_2_enc: torch.Tensor,
                        plain: AlicePlain, l: int, scheme_paillier: Paillier) -> torch.Tensor:
-        """Steps 6 and 7 together with ONE inversion pass instead of two, yielding the same residues:
-        [[x<=y]] = [[zeta]] * ([[r div 2^l]] * [[beta<alpha]])^-1 with [[beta<alpha]] = [[delta_B]] (delta_A = 1) or
+        """Steps 6 and 7 in one library call (sc_initiator_step67) with ONE inversion pass instead of two, yielding the same
+        residues: [[x<=y]] = [[zeta]] * ([[r div 2^l]] * [[beta<alpha]])^-1 with [[beta<alpha]] = [[delta_B]] (delta_A = 1) or
         [[1]] [[delta_B]]^-1 (delta_A = 0) equals [[zeta]] * D * [[-(r div 2^l) - (1 - delta_A)]] with D = [[delta_B]]^-1
         (delta_A = 1) or [[delta_B]] (delta_A = 0), because [[a]] [[b]] = [[a + b]] holds exactly for unrandomized
         g = N + 1 encryptions (SC/initiator.py:529-531, 558-563)."""
-        e, pai = scheme_paillier.engine, scheme_paillier
-        n = pai.public_key.n
-        sel = (delta_a != 0).reshape(-1, 1)
-        d_factor = torch.where(sel, pai.neg_batch(delta_b_enc), delta_b_enc).contiguous()
-        neg_r = pai.encrypt_raw_neg_batch(plain.r_shift)                                   # [[-(r div 2^l)]]
-        neg_r_1 = e.modmul_const(pai.mod_n2, neg_r, (1 - n) % (n * n))                     # * [[-1]]
-        corr = torch.where(sel, neg_r, neg_r_1).contiguous()
-        zeta = torch.where((plain.r_small != 0).reshape(-1, 1), zeta_1_enc, zeta_2_enc).contiguous()
-        return pai.add_batch(pai.add_batch(zeta, d_factor), corr)
+        return scheme_paillier.engine.initiator_step67(scheme_paillier.key, delta_a, delta_b_enc, zeta_1_enc, zeta_2_enc, plain.r_small,
+                                                       plain.r_shift)

@@ -298,8 +298,7 @@ class Paillier(_Scheme):
                 raise ValueError("p * q != n")
             lam = (p - 1) * (q - 1)
             self.secret_key = _PublicKey(p=p, q=q, lambda_=lam, mu=pow(lam, -1, n))
-        self._m_n = None
-        self._m_n2 = None
+        self._key = None
 
     @classmethod
     def from_security_parameter(cls, key_length: int = 2048, engine=None, precision: int = 0, **_ignored: Any) -> "Paillier":
@@ -317,16 +316,21 @@ class Paillier(_Scheme):
 
     # ---- engine handles
     @property
+    def key(self):
+        """The library-side key object (sc_paillier_key_create): moduli, exponents, CRT constants -- derived once, in the library."""
+        if self._key is None:
+            sk = self.secret_key
+            self._key = self.engine.paillier_key(self.public_key.n, None if sk is None else sk.p, None if sk is None else sk.q,
+                                                 use_crt=self.use_crt, use_pairs=self.use_pairs)
+        return self._key
+
+    @property
     def mod_n(self):
-        if self._m_n is None:
-            self._m_n = self.engine.modulus(self.public_key.n)
-        return self._m_n
+        return self.key.mod_n
 
     @property
     def mod_n2(self):
-        if self._m_n2 is None:
-            self._m_n2 = self.engine.modulus(self.public_key.n_squared, 2 * self.mod_n.nwords)
-        return self._m_n2
+        return self.key.mod_n2
 
     @property
     def _ct_mod(self):
@@ -340,97 +344,35 @@ class Paillier(_Scheme):
         v = m - self.public_key.n if m > self.public_key.n // 2 else m
         return v if self.precision == 0 else v / 10 ** self.precision
 
-    # ---- batched API (device tensors [count][words])
+    # ---- batched API (device tensors [count][words]): one library call each
     def encrypt_raw_batch(self, m_words: torch.Tensor) -> torch.Tensor:
         """[[m]] = 1 + m N mod N^2 without randomness, for plaintext words [count][<= 2*nw]."""
-        return self.engine.paillier_encrypt_raw(self.mod_n2, self.public_key.n, m_words)
+        return self.engine.paillier_encrypt(self.key, m_words)
 
     def encrypt_raw_neg_batch(self, m_words: torch.Tensor) -> torch.Tensor:
         """[[-m]] = 1 - m N mod N^2 = ([[m]])^-1, with no modular inversion."""
-        return self.engine.paillier_encrypt_raw_neg(self.mod_n2, self.public_key.n, m_words)
+        return self.engine.paillier_encrypt(self.key, m_words, negate=True)
 
     def randomizer_batch(self, rho: torch.Tensor) -> torch.Tensor:
         """rho^N mod N^2 for rho words [count][nw(N)]."""
         return self.randomize_batch(None, rho)
 
     def randomize_batch(self, c: torch.Tensor | None, rho: torch.Tensor) -> torch.Tensor:
-        """c * rho^N mod N^2 (c = None: just the randomizer).  The key holder uses CRT (identical integers)."""
-        e = self.engine
-        n = self.public_key.n
-        if self.secret_key is not None and self.use_crt:
-            rn = self._crt_pow_n(rho)
-            return rn if c is None else e.modmul(self.mod_n2, c, rn)
-        if self.use_pairs and e.supports_sq(self.mod_n):
-            return e.modexp_shared_sq(self.mod_n, self.mod_n2, rho, n, mul_into=c)   # arithmetic modulo N only
-        if rho.shape[-1] != self.mod_n2.nwords:
-            rho = torch.nn.functional.pad(rho, (0, self.mod_n2.nwords - rho.shape[-1]))
-        return e.modexp_shared(self.mod_n2, rho, n, mul_into=c)
+        """c * rho^N mod N^2 (c = None: just the randomizer): sc_paillier_randomize.  The key holder's key goes through CRT over
+        p^2, q^2 inside the library (identical integers); Alice's through the pair arithmetic modulo N."""
+        return self.engine.paillier_randomize(self.key, c, rho)
 
     def decrypt_raw_batch(self, c: torch.Tensor) -> torch.Tensor:
-        """m = L(c^lambda mod N^2) mu mod N, words [count][nw(N)] (SC/keyholder.py:195)."""
+        """m = L(c^lambda mod N^2) mu mod N, words [count][nw(N)] (SC/keyholder.py:195): sc_paillier_decrypt."""
         if self.secret_key is None:
             raise ValueError("this Paillier scheme has no secret key")
-        e = self.engine
-        if self.use_crt:
-            return self._crt_decrypt(c)
-        if self.use_pairs and e.supports_sq(self.mod_n):
-            x = e.modexp_shared_sq(self.mod_n, self.mod_n2, c, self.secret_key.lambda_)
-        else:
-            x = e.modexp_shared(self.mod_n2, c, self.secret_key.lambda_)
-        return e.paillier_l_mul(self.mod_n, self.secret_key.mu, x)
+        return self.engine.paillier_decrypt(self.key, c)
 
     def add_batch(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
         return self.engine.modmul(self.mod_n2, a, b)
 
     def neg_batch(self, a: torch.Tensor) -> torch.Tensor:
         return self.engine.modinv(self.mod_n2, a)
-
-    # ---- CRT paths of the key holder (bit-identical results, ~3-4x fewer limb products)
-    def _crt_setup(self):
-        if getattr(self, "_crt", None) is None:
-            e, sk = self.engine, self.secret_key
-            p, q, n = sk.p, sk.q, self.public_key.n
-            nw = self.mod_n.nwords
-            hw = (max(p.bit_length(), q.bit_length()) + 31) // 32
-            crt = {"hw": hw}
-            for name, pr, other in (("p", p, q), ("q", q, p)):
-                crt[name] = {
-                    "m1": e.modulus(pr, hw),                    # mod p
-                    "m2": e.modulus(pr * pr, 2 * hw),           # mod p^2
-                    # decryption: m_p = L_p(c^(p-1) mod p^2) * h_p mod p,  h_p = L_p((N+1)^(p-1) mod p^2)^-1 mod p
-                    "h": pow((pow(n + 1, pr - 1, pr * pr) - 1) // pr, -1, pr),
-                    # randomizer: rho^N mod p^2 = ((rho mod p)^(q mod (p-1)) mod p)^p mod p^2   (x^p mod p^2 depends on x mod p only)
-                    "e_small": other % (pr - 1),
-                }
-            self._crt = crt
-        return self._crt
-
-    def _crt_pow_n(self, rho: torch.Tensor) -> torch.Tensor:
-        """rho^N mod N^2 by CRT over p^2, q^2."""
-        e, sk, crt = self.engine, self.secret_key, self._crt_setup()
-        p, q = sk.p, sk.q
-        parts = {}
-        for name, pr in (("p", p), ("q", q)):
-            c = crt[name]
-            y = e.modexp_shared(c["m1"], rho, c["e_small"])                 # (rho mod p)^(q mod p-1) mod p  (wide input reduced)
-            if self.use_pairs and e.supports_sq(c["m1"]):
-                parts[name] = e.modexp_shared_sq(c["m1"], c["m2"], y, pr)                # y^p mod p^2 with products mod p
-            else:
-                parts[name] = e.modexp_shared(c["m2"], torch.nn.functional.pad(y, (0, c["m2"].nwords - y.shape[-1])), pr)
-        return e.crt_combine(crt["p"]["m2"], self.mod_n2, q * q, parts["p"], parts["q"])
-
-    def _crt_decrypt(self, c: torch.Tensor) -> torch.Tensor:
-        e, sk, crt = self.engine, self.secret_key, self._crt_setup()
-        p, q = sk.p, sk.q
-        ms = {}
-        for name, pr in (("p", p), ("q", q)):
-            cc = crt[name]
-            if self.use_pairs and e.supports_sq(cc["m1"]):
-                x = e.modexp_shared_sq(cc["m1"], cc["m2"], c, pr - 1)       # c^(p-1) mod p^2 with products mod p
-            else:
-                x = e.modexp_shared(cc["m2"], c, pr - 1)                   # c^(p-1) mod p^2 (wide input reduced)
-            ms[name] = e.paillier_l_mul(cc["m1"], cc["h"], x)              # L_p(x) * h_p mod p
-        return e.crt_combine(crt["p"]["m1"], self.mod_n, q, ms["p"], ms["q"])
 
     # ---- single-ciphertext API of the reference
     def _unsafe_encrypt_raw_value(self, m: int) -> int:
@@ -486,7 +428,7 @@ class DGK(_Scheme):
         self.full_decryption = full_decryption
         self.randomizer_bits = randomizer_bits if randomizer_bits is not None else int(2.5 * t)
         self.fixed_base_window = fixed_base_window
-        self._m_n = self._m_p = self._fb_h = None
+        self._key = None
         self._table_source: "DGK | None" = None
         self.table_build_s = 0.0
         self._g_inv = None
@@ -510,18 +452,36 @@ class DGK(_Scheme):
     __hash__ = None  # type: ignore[assignment]
 
     @property
+    def key(self):
+        """The library-side key object (sc_dgk_key_create): moduli, g^-1, the CRT halves and the fixed-base tables for h --
+        built on first use, or taken over read-only from the scheme object named by share_tables_from."""
+        if self._key is None:
+            import time
+
+            pk, sk, src = self.public_key, self.secret_key, self._table_source
+            t0 = time.perf_counter()
+            self._key = self.engine.dgk_key(pk.n, pk.g, pk.h, pk.u, pk.t, *((None,) * 4 if sk is None else (sk.p, sk.q, sk.v_p, sk.v_q)),
+                                            randomizer_bits=self.randomizer_bits, window=self.fixed_base_window, use_crt=self.use_crt,
+                                            table_source=None if src is None else (src.engine, src.key))
+            self.engine.synchronize()
+            if src is None:
+                self.table_build_s += time.perf_counter() - t0
+        return self._key
+
+    def prepare(self) -> "DGK":
+        """Build (or import) the key object and its tables now -- untimed set-up, like key generation."""
+        _ = self.key
+        return self
+
+    @property
     def mod_n(self):
-        if self._m_n is None:
-            self._m_n = self.engine.modulus(self.public_key.n)
-        return self._m_n
+        return self.key.mod_n
 
     @property
     def mod_p(self):
-        if self._m_p is None:
-            if self.secret_key is None:
-                raise ValueError("this DGK scheme has no secret key")
-            self._m_p = self.engine.modulus(self.secret_key.p)
-        return self._m_p
+        if self.secret_key is None:
+            raise ValueError("this DGK scheme has no secret key")
+        return self.key.mod_p
 
     @property
     def _ct_mod(self):
@@ -530,43 +490,21 @@ class DGK(_Scheme):
     @property
     def g_inv(self) -> int:
         if self._g_inv is None:
-            self._g_inv = self._inv_value(self.public_key.g)
+            self._g_inv = pow(self.public_key.g, -1, self.public_key.n)     # set-up constant (the library derives its own copy)
         return self._g_inv
-
-    @property
-    def fb_h(self):
-        """Fixed-base table for h (randomizers h^r).  Built on first use -- or taken over from the scheme object named by
-        share_tables_from (another library context on the same GPU reads the same rows)."""
-        if self._fb_h is None:
-            src = self._table_source
-            if src is not None:
-                self._fb_h = self.engine.fixed_base_import(self.mod_n, src.engine, src.fb_h)
-            else:
-                import time
-
-                t0 = time.perf_counter()
-                self._fb_h = self.engine.fixed_base(self.mod_n, self.public_key.h, self.randomizer_bits, self.fixed_base_window)
-                self.engine.synchronize()
-                self.table_build_s += time.perf_counter() - t0
-        return self._fb_h
 
     def share_tables_from(self, other: "DGK") -> None:
         """Read `other`'s device-resident fixed-base tables instead of building copies (same key, window and randomizer
         width; `other` may be bound to another engine of the same GPU -- the concurrent shards of batch.ConcurrentShards)."""
         if other.public_key != self.public_key or other.fixed_base_window != self.fixed_base_window or \
-                other.randomizer_bits != self.randomizer_bits or (other.secret_key is None) != (self.secret_key is None):
+                other.randomizer_bits != self.randomizer_bits or (other.secret_key is None) != (self.secret_key is None) or \
+                other.use_crt != self.use_crt:
             raise ValueError("tables can only be shared between scheme objects of the same key and table parameters")
         self._table_source = other
 
     def table_bytes(self) -> int:
-        """Device bytes of the fixed-base tables this object has built or taken over so far."""
-        e = self.engine
-        total = e.fixed_base_bytes(self._fb_h) if self._fb_h is not None else 0
-        for name in ("p", "q"):
-            k = (getattr(self, "_crt", None) or {}).get(name)
-            if k:
-                total += e.fixed_base_bytes(k["fb"])
-        return total
+        """Device bytes of the fixed-base tables of this object's key (built or taken over)."""
+        return 0 if self._key is None else self.engine.dgk_table_bytes(self._key)
 
     def _encode(self, m: Any) -> int:
         if isinstance(m, float):
@@ -575,7 +513,7 @@ class DGK(_Scheme):
             m = int(m)
         return int(m)
 
-    # ---- batched API
+    # ---- batched API: one library call each
     def encrypt_bits_batch(self, bits: torch.Tensor) -> torch.Tensor:
         """g^b for b in {0,1}: words [count][nw] (SC/keyholder.py:213, 231)."""
         e = self.engine
@@ -585,57 +523,22 @@ class DGK(_Scheme):
 
     def encrypt_bits_randomized_batch(self, bits: torch.Tensor, r: torch.Tensor) -> torch.Tensor:
         """g^b * h^r for bits b [count] and exponent words r [count][ewords]: `unsafe_encrypt(bit)` and `.randomize()` of
-        SC/keyholder.py:213, 231 and :106-108 in one go -- the randomizer h^r times the constant g or 1, chosen per item by a
-        byte flag inside the launch (no array of g^b is materialised)."""
-        hr = self.randomize_batch(None, r)
-        flags = (bits.reshape(-1) != 0).to(torch.uint8)
-        return self.engine.modmul_const_sel(self.mod_n, hr, None, self.public_key.g, flags, out=hr)
+        SC/keyholder.py:213, 231 and :106-108 in one library call (sc_dgk_encrypt_bits_randomized)."""
+        return self.engine.dgk_encrypt_bits_randomized(self.key, (bits.reshape(-1) != 0).to(torch.uint8), r)
 
     def randomize_batch(self, c: torch.Tensor | None, r: torch.Tensor) -> torch.Tensor:
-        """c * h^r mod n for exponent words r [count][ewords] (SC/keyholder.py:106-108; SC/initiator.py:153-154).
-        The key holder (who knows p, q, v_p, v_q) goes through CRT: h has order v_p modulo p, so h^r mod p =
-        h^(r mod v_p) mod p -- a 160-bit exponent and a half-size modulus per prime, recombined on the GPU; identical
-        residues, about a third of the limb products."""
-        e = self.engine
-        if self.secret_key is None or not self.use_crt:
-            return e.fixedbase_pow(self.fb_h, r, mul_into=c)
-        crt = self._crt_setup()
-        parts = {}
-        for name in ("p", "q"):
-            k = crt[name]
-            r_red = e.modexp_shared(k["m_v"], r, 1)                       # r mod v  (wide operand reduced)
-            parts[name] = e.fixedbase_pow(k["fb"], r_red)                 # h^(r mod v) mod prime
-        hr = e.crt_combine(crt["p"]["m"], self.mod_n, self.secret_key.q, parts["p"], parts["q"])
-        return hr if c is None else e.modmul(self.mod_n, c, hr)
-
-    def _crt_setup(self):
-        if getattr(self, "_crt", None) is None:
-            e, sk, pk = self.engine, self.secret_key, self.public_key
-            import time
-
-            crt = {}
-            src = self._table_source
-            for name, prime, v in (("p", sk.p, sk.v_p), ("q", sk.q, sk.v_q)):
-                m = e.modulus(prime)
-                if src is not None:
-                    fb = e.fixed_base_import(m, src.engine, src._crt_setup()[name]["fb"])
-                else:
-                    t0 = time.perf_counter()
-                    fb = e.fixed_base(m, pk.h % prime, v.bit_length(), min(self.fixed_base_window, 16))
-                    e.synchronize()
-                    self.table_build_s += time.perf_counter() - t0
-                crt[name] = {"m": m, "m_v": e.modulus(v), "fb": fb}
-            self._crt = crt
-        return self._crt
+        """c * h^r mod n for exponent words r [count][ewords] (SC/keyholder.py:106-108; SC/initiator.py:153-154):
+        sc_dgk_randomize.  The key holder's key goes through CRT inside the library (h has order v_p modulo p: a 160-bit
+        exponent and a half-size modulus per prime); identical residues."""
+        return self.engine.dgk_randomize(self.key, c, r)
 
     def is_zero_batch(self, c: torch.Tensor) -> torch.Tensor:
         """uint8 flags: plaintext == 0 mod u (SC/keyholder.py:249)."""
-        return self.engine.modexp_shared_isone(self.mod_p, c, self.secret_key.v_p)
+        return self.engine.dgk_is_zero(self.key, c)
 
     def any_zero_batch(self, c: torch.Tensor) -> torch.Tensor:
         """int64 [B]: 1 where some plane of the bit-major vector c [planes][B][nw] decrypts to 0 mod u (KeyHolder.step_4j)."""
-        planes, count, nw = c.shape
-        return self.engine.modexp_shared_isone_any(self.mod_p, c.reshape(planes * count, nw), self.secret_key.v_p, count)
+        return self.engine.dgk_any_zero(self.key, c)
 
     def neg_batch(self, c: torch.Tensor) -> torch.Tensor:
         return self.engine.modinv(self.mod_n, c)

@@ -64,6 +64,10 @@ def _header(t: torch.Tensor) -> bytes:
 
 def _pack(tensors: Sequence[torch.Tensor], framed: bool) -> memoryview:
     """One host buffer for the whole message; every payload lands in it by a single copy from wherever the array lives."""
+    for t in tensors:
+        if t.is_cuda:     # the copies below wait for the producing kernels anyway; waiting here keeps STATS about the wire only
+            torch.cuda.current_stream(t.device).synchronize()
+            break
     t0 = time.perf_counter()
     heads = [_header(t) for t in tensors]
     sizes = [len(h) + t.numel() * t.element_size() for h, t in zip(heads, tensors)]

@@ -27,6 +27,27 @@ class FixedBase:
     base: int
 
 
+@dataclass(frozen=True)
+class PaillierKey:
+    id: int
+    mod_n: Modulus
+    mod_n2: Modulus
+    secret: bool
+    sk: object = None          # oracle PaillierKey (test stand-in only)
+
+
+@dataclass(frozen=True)
+class DgkKey:
+    id: int
+    mod_n: Modulus
+    mod_p: object
+    u: int
+    randomizer_bits: int
+    window: int
+    secret: bool
+    sk: object = None          # oracle DGKKey
+
+
 class OracleEngine:
     device = torch.device("cpu")
 
@@ -69,6 +90,116 @@ class OracleEngine:
 
         call = self._rng_next_call()
         return torch.tensor(c.rng_permutations(self._rng_key, call, k, count), dtype=torch.int64).reshape(count, k)
+
+    # ---- scheme-level entry points (the library composes these from its kernels; here: the oracle's integers)
+    def paillier_key(self, n, p=None, q=None, use_crt=True, use_pairs=True):
+        nw = (n.bit_length() + 31) // 32
+        return PaillierKey(0, self.modulus(n, nw), self.modulus(n * n, 2 * nw), p is not None, o.PaillierKey(n, p, q))
+
+    def paillier_encrypt(self, key, m, negate=False, out=None):
+        n, n2 = key.mod_n.n, key.mod_n2.n
+        return self.upload([(1 + (-(v % n) if negate else (v % n)) * n) % n2 for v in self._ints(m)], key.mod_n2.nwords)
+
+    def paillier_randomize(self, key, c, rho, out=None):
+        n, n2 = key.mod_n.n, key.mod_n2.n
+        r = [pow(v, n, n2) for v in self._ints(rho)]
+        if c is not None:
+            r = [a * b % n2 for a, b in zip(self._ints(c), r)]
+        return self.upload(r, key.mod_n2.nwords)
+
+    def paillier_decrypt(self, key, c):
+        return self.upload([key.sk.dec_raw(v) for v in self._ints(c)], key.mod_n.nwords)
+
+    def dgk_key(self, n, g, h, u, t, p=None, q=None, v_p=None, v_q=None, randomizer_bits=400, window=8, use_crt=True, table_source=None):
+        nw = (n.bit_length() + 31) // 32
+        sk = o.DGKKey(n, g, h, u, t, p, q, v_p, v_q)
+        return DgkKey(0, self.modulus(n, nw), None if p is None else self.modulus(p), u, randomizer_bits, window, p is not None, sk)
+
+    def dgk_table_bytes(self, key):
+        return 1
+
+    def dgk_randomize(self, key, c, r, out=None):
+        n = key.mod_n.n
+        hr = [pow(key.sk.h, v, n) for v in self._ints(r)]
+        if c is not None:
+            hr = [a * b % n for a, b in zip(self._ints(c), hr)]
+        return self.upload(hr, key.mod_n.nwords)
+
+    def dgk_encrypt_bits_randomized(self, key, bits, r):
+        n = key.mod_n.n
+        return self.upload([(key.sk.g if b else 1) * pow(key.sk.h, v, n) % n for b, v in zip(bits.tolist(), self._ints(r))], key.mod_n.nwords)
+
+    def dgk_is_zero(self, key, c):
+        return self.modexp_shared_isone(key.mod_p, c, key.sk.v_p)
+
+    def dgk_any_zero(self, key, c):
+        planes, count, nw = c.shape
+        return self.modexp_shared_isone_any(key.mod_p, c.reshape(planes * count, nw), key.sk.v_p, count)
+
+    def initiator_step1(self, key, l, x_enc, y_enc, r, rho_z=None):
+        n, n2 = key.mod_n.n, key.mod_n2.n
+        m1, alpha, alpha_t, rsmall, rshift = self.plain_alice(r, n, l)
+        z = self.modmul(key.mod_n2, self.modmul(key.mod_n2, y_enc, self.modinv(key.mod_n2, x_enc)), self.paillier_encrypt(key, m1))
+        if rho_z is not None:
+            z = self.paillier_randomize(key, z, rho_z)
+        return z, alpha, alpha_t, rsmall, rshift
+
+    def keyholder_step2_4b(self, pkey, dkey, l, z_enc, r_rand=None):
+        count = z_enc.shape[0]
+        z = self.paillier_decrypt(pkey, z_enc)
+        beta, dbit, zeta1, zeta2 = self.plain_bob(z, pkey.mod_n.n, l)
+        M = (1 << 64) - 1
+        bits = [int(v) & 1 for v in dbit.tolist()]
+        for i in range(l):
+            bits += [((int(v) & M) >> i) & 1 for v in beta.tolist()]
+        bt = torch.tensor(bits, dtype=torch.uint8)
+        if r_rand is not None:
+            enc = self.dgk_encrypt_bits_randomized(dkey, bt, r_rand)
+        else:
+            enc = self.upload([dkey.sk.g if b else 1 for b in bits], dkey.mod_n.nwords)
+        return z, beta, dbit, zeta1, zeta2, enc.reshape(l + 1, count, -1)
+
+    def initiator_step4i(self, key, l, c_in, rhos, permutation=None, r_rand=None):
+        lp1, count, nw = c_in.shape
+        dest = None
+        if permutation is not None:
+            planes = torch.arange(lp1, dtype=torch.int64).expand(count, lp1)
+            inverse = torch.zeros_like(permutation).scatter_(1, permutation.clamp(0, lp1 - 1), planes)
+            dest = (inverse.t() * count + torch.arange(count, dtype=torch.int64)).reshape(-1)
+        fb = FixedBase(0, key.mod_n, key.sk.h) if r_rand is not None else None
+        flat = self.modexp_var(key.mod_n, c_in.reshape(lp1 * count, nw), rhos.reshape(lp1 * count, -1), 0, fb,
+                               None if r_rand is None else r_rand.reshape(lp1 * count, -1), dest=dest)
+        return flat.reshape(lp1, count, nw)
+
+    def initiator_step4(self, key, l, d_enc, beta_enc, alpha, alpha_tilde, rsmall, delta_a, rhos=None, permutation=None, r_rand=None,
+                        want_unblinded=False):
+        count, nw = d_enc.shape
+        inv = self.modinv(key.mod_n, torch.cat([d_enc.reshape(1, count, nw), beta_enc]).reshape((l + 1) * count, nw))
+        c_h = self.dgk_step4(key.mod_n, key.sk.g, o.mod_inv(key.sk.g, key.mod_n.n), l, beta_enc, inv[count:].reshape(l, count, nw), d_enc,
+                             inv[:count], alpha, alpha_tilde, rsmall, delta_a)
+        if rhos is None:
+            return c_h, None
+        return self.initiator_step4i(key, l, c_h, rhos, permutation, r_rand), (c_h if want_unblinded else None)
+
+    def keyholder_step4j_5(self, pkey, dkey, l, c_enc, zeta1, zeta2, rho3=None):
+        count = zeta1.shape[0]
+        delta_b = self.dgk_any_zero(dkey, c_enc.reshape(l + 1, count, -1))
+        db = self.upload([int(v) for v in delta_b.tolist()], zeta1.shape[-1])
+        enc = self.paillier_encrypt(pkey, torch.cat([zeta1, zeta2, db], dim=0))
+        if rho3 is not None:
+            enc = self.paillier_randomize(pkey, enc, rho3)
+        return delta_b, enc
+
+    def initiator_step67(self, key, delta_a, delta_b_enc, zeta1_enc, zeta2_enc, rsmall, rshift):
+        # the LITERAL formulas of SC/initiator.py:529-531, 558-563 (two inversions): the library's one-inversion form must equal them
+        n, n2 = key.mod_n.n, key.mod_n2.n
+        out = []
+        for da, db, z1, z2, rs, sh in zip(delta_a.tolist(), self._ints(delta_b_enc), self._ints(zeta1_enc), self._ints(zeta2_enc),
+                                          rsmall.tolist(), self._ints(rshift)):
+            blta = db if da else (1 + n) * o.mod_inv(db, n2) % n2
+            zeta = z1 if rs else z2
+            out.append(zeta * o.mod_inv((1 + sh * n) % n2 * blta % n2, n2) % n2)
+        return self.upload(out, key.mod_n2.nwords)
 
     # ---- plumbing
     def upload(self, xs, nwords):

@@ -118,7 +118,7 @@ def test_the_configuration_bench_times(engine, keys):
         if i > 0:
             bob_d.share_tables_from(sets[0].bob_dgk)
             alice_d.share_tables_from(sets[0].alice_dgk)
-        _ = alice_d.fb_h, bob_d._crt_setup()
+        alice_d.prepare(), bob_d.prepare()
         sets.append(PartySet(bob_p.public_copy(), alice_d, bob_p, bob_d, torch.cuda.Stream()))
     p0 = sets[0]
     x, y, x_enc, y_enc, draws = bench.synth_inputs(engines[0], l, p0.alice_paillier, p0.bob_paillier, p0.bob_dgk, B, rbits, seed=3, shuffle=True)

@@ -4,8 +4,8 @@ library (A/B on the same box):
     python tools/gpu_kernel_rates.py [lib.so ...]        # default: the in-tree library
 
 Each build runs in its own child process (SC_AMD_LIB).  Shapes are those of BASELINE configs[2] (B = 65536, l = 32,
-2048-bit keys): Alice's rho^N (k_pvm<4,18>), the key holder's CRT halves (k_vm<2,18> then k_pvm<2,18> over 3B items),
-the zero tests (k_vm<2,18>, 33B items), blinding + re-randomization (k_vm<4,18>, 33B items), decrypt (k_pvm<2,18>).
+2048-bit keys): Alice's rho^N (k_pvm<4,18>), the key holder's CRT halves (k_vm<1,37> one-lane -- k_vm<2,18> below 196608 items -- then k_pvm<2,18> over 3B items),
+the zero tests (k_vm<1,37>, 33B items), blinding + re-randomization (k_vm<4,18>, 33B items), decrypt (k_pvm<2,18>).
 """
 import json
 import os
@@ -37,11 +37,16 @@ def child() -> None:
     bob_d = DGK(H("p") * H("q"), H("g"), H("h"), H("u"), dj["t"], H("p"), H("q"), H("v_p"), H("v_q"), randomizer_bits=rbits, fixed_base_window=16)
     alice_d = bob_d.public_copy()
     x, y, x_enc, y_enc, draws = bench.synth_inputs(eng, l, alice_p, bob_p, bob_d, B, rbits, 0)
-    crt = bob_p._crt_setup()
+    from protocols.secure_comparison_amd import Initiator
+
+    hw = (max(p.bit_length(), q.bit_length()) + 31) // 32
+    m_p, m_p2, e_small = eng.modulus(p, hw), eng.modulus(p * p, 2 * hw), q % (p - 1)   # the primitives behind the key holder's CRT
     rho3 = torch.cat([draws.rho_zeta_1, draws.rho_zeta_2, draws.rho_delta_b], dim=0)
     nwd = alice_d.mod_n.nwords
     c33 = alice_d.randomize_batch(None, draws.r_alice_dgk.reshape((l + 1) * B, -1))
-    y_p = eng.modexp_shared(crt["p"]["m1"], rho3, crt["p"]["e_small"])
+    c33p = c33.reshape(l + 1, B, nwd)
+    y_p = eng.modexp_shared(m_p, rho3, e_small)
+    one_lane = 3 * B >= 196608
     out = {}
 
     def rate(name, fn, reps=2):
@@ -57,15 +62,14 @@ def child() -> None:
         ms = e0.elapsed_time(e1) / reps
         out[name] = {"ms": round(ms, 3), "T_mac_s": round(eng.mac_counter() / reps / ms / 1e9, 3)}
 
-    rate("alice rho^N mod N^2  (k_pvm<4,18>, B)", lambda: alice_p.randomize_batch(x_enc, draws.rho_z))
-    rate("bob (rho mod p)^e mod p  (k_vm<2,18>, 3B)", lambda: eng.modexp_shared(crt["p"]["m1"], rho3, crt["p"]["e_small"]))
-    rate("bob y^p mod p^2  (k_pvm<2,18>, 3B)", lambda: eng.modexp_shared_sq(crt["p"]["m1"], crt["p"]["m2"], y_p, p))
+    rate("alice rho^N mod N^2  (k_pvm<4,18>+k_vm<8,18>, B)", lambda: alice_p.randomize_batch(x_enc, draws.rho_z))
+    rate("bob (rho mod p)^e mod p  (%s, 3B)" % ("k_vm<1,37>" if one_lane else "k_vm<2,18>"), lambda: eng.modexp_shared(m_p, rho3, e_small))
+    rate("bob y^p mod p^2  (k_pvm<2,18>, 3B)", lambda: eng.modexp_shared_sq(m_p, m_p2, y_p, p))
     rate("bob 3 randomizers, whole CRT path (3B)", lambda: bob_p.randomize_batch(None, rho3))
     rate("bob decrypt, whole CRT path (B)", lambda: bob_p.decrypt_raw_batch(x_enc))
-    rate("zero tests (k_vm<2,18>, 33B)", lambda: bob_d.is_zero_batch(c33))
-    rate("blind + rerandomize (k_vm<4,18>, 33B)", lambda: eng.modexp_var(alice_d.mod_n, c33, draws.rhos.reshape((l + 1) * B, -1), 35, alice_d.fb_h,
-                                                                        draws.r_alice_dgk.reshape((l + 1) * B, -1)))
-    rate("bob DGK randomizers h^r, CRT (33B)", lambda: bob_d.randomize_batch(None, draws.r_bob_dgk.reshape((l + 1) * B, -1)))
+    rate("zero tests + delta_B (k_vm<1,37>, 33B)", lambda: bob_d.any_zero_batch(c33p))
+    rate("blind + rerandomize, 4i (k_vm<4,18>, 33B)", lambda: Initiator.step_4i_batch(c33p, alice_d, draws.rhos, None, draws.r_alice_dgk))
+    rate("bob g^b h^r, CRT (k_vm<2,18>, 33B)", lambda: bob_d.randomize_batch(None, draws.r_bob_dgk.reshape((l + 1) * B, -1)))
     rate("inversions mod n (33B)", lambda: alice_d.neg_batch(c33))
     rate("inversion mod N^2 (B)", lambda: alice_p.neg_batch(x_enc))
     print(json.dumps(out))

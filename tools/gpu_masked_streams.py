@@ -44,7 +44,7 @@ for i in range(NS):
     eng = Engine()
     bob_p = Paillier(p * q, p, q, engine=eng); alice_p = bob_p.public_copy()
     bob_d = DGK(H("p") * H("q"), H("g"), H("h"), H("u"), dj["t"], H("p"), H("q"), H("v_p"), H("v_q"), engine=eng, randomizer_bits=rbits, fixed_base_window=20)
-    alice_d = bob_d.public_copy(); _ = bob_d.fb_h, alice_d.fb_h
+    alice_d = bob_d.public_copy(); bob_d.prepare(), alice_d.prepare()
     x, y, xe, ye, dr = bench.synth_inputs(eng, l, alice_p, bob_p, bob_d, B // NS, rbits, i)
     parts.append(dict(ap=alice_p, ad=alice_d, bp=bob_p, bd=bob_d, x=x, y=y, xe=xe, ye=ye, dr=dr, stream=streams[i]))
 torch.cuda.synchronize()

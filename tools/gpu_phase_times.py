@@ -17,7 +17,7 @@ p, q = int(pj["p"], 16), int(pj["q"], 16)
 eng = default_engine()
 bob_p = Paillier(p * q, p, q); alice_p = bob_p.public_copy()
 bob_d = DGK(int(dj["p"], 16) * int(dj["q"], 16), int(dj["g"], 16), int(dj["h"], 16), int(dj["u"], 16), dj["t"], int(dj["p"], 16), int(dj["q"], 16), int(dj["v_p"], 16), int(dj["v_q"], 16), randomizer_bits=rbits, fixed_base_window=fbw)
-alice_d = bob_d.public_copy(); _ = alice_d.fb_h
+alice_d = bob_d.public_copy(); alice_d.prepare()
 x, y, x_enc, y_enc, draws = bench.synth_inputs(eng, l, alice_p, bob_p, bob_d, B, rbits, 0)
 times, macs = {}, {}
 def timed(name, fn):

@@ -15,7 +15,7 @@ eng = default_engine()
 bob_p = Paillier(p * q, p, q); alice_p = bob_p.public_copy()
 H = lambda k: int(dj[k], 16)
 bob_d = DGK(H("p") * H("q"), H("g"), H("h"), H("u"), dj["t"], H("p"), H("q"), H("v_p"), H("v_q"), randomizer_bits=rbits, fixed_base_window=20)
-alice_d = bob_d.public_copy(); _ = bob_d.fb_h, alice_d.fb_h
+alice_d = bob_d.public_copy(); bob_d.prepare(), alice_d.prepare()
 x, y, x_enc, y_enc, draws = bench.synth_inputs(eng, l, alice_p, bob_p, bob_d, B, rbits, 0)
 for i in range(steps):
     torch.cuda.synchronize(); t0 = time.perf_counter()
