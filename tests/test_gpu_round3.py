@@ -170,3 +170,131 @@ def test_interactive_batch_protocol_at_scale(engine, keys, device_tensors):
         assert (wire.STATS["bytes"] == 0) == device_tensors
         outs.append(res)
     assert not bool((outs[0] == outs[1]).all(dim=1).any().item())
+
+
+def test_scheme_level_c_abi_with_ctypes_only(keys):
+    """The scheme-level entry points of include/sc_amd.h driven the way INTEGRATION.md's stub drives them: ctypes, sc_malloc /
+    sc_memcpy_*, no torch and none of this package's scheme classes.  A whole batch of comparisons is five library calls
+    (sc_initiator_step1, sc_keyholder_step2_4b, sc_initiator_step4, sc_keyholder_step4j_5, sc_initiator_step67); every
+    intermediate and the result are compared with the oracle bit for bit, for the key holder's CRT and literal paths."""
+    import ctypes as C
+
+    import numpy as np
+
+    from oracle import sc_oracle as o
+    from protocols.secure_comparison_amd import _lib
+    from protocols.secure_comparison_amd.limbs import ints_to_words, words_to_ints
+
+    lib = _lib.load()
+    sk, dgk = oracle_paillier(keys, 1024), oracle_dgk(keys, "dgk_1024_l16")
+    l, B, rbits = 16, 21, 400
+    nw, nd, ew, er = 32, 32, (dgk.u.bit_length() + 31) // 32, (rbits + 31) // 32
+    rng = random.Random(12)
+    xs = [rng.randrange(1 << l) for _ in range(B)]
+    ys = [xs[i] if i % 4 == 0 else rng.randrange(1 << l) for i in range(B)]
+    drs = [o.draw(rng, l, sk, dgk, rbits) for _ in range(B)]
+    x_enc = [sk.randomize(sk.enc_raw(x), 1 + rng.randrange(sk.n - 1)) for x in xs]
+    y_enc = [sk.randomize(sk.enc_raw(y), 1 + rng.randrange(sk.n - 1)) for y in ys]
+    traces = [dict() for _ in range(B)]
+    expect = [o.compare(a, b, l, sk, dgk, d, True, t) for a, b, d, t in zip(x_enc, y_enc, drs, traces)]
+
+    def words(v, w):
+        a = ints_to_words([v], w)
+        return a, a.ctypes.data_as(C.c_void_p)
+
+    for flags in (0, 1):          # 1 = SC_KEY_NO_CRT
+        ctx = C.c_void_p()
+        assert lib.sc_ctx_create(0, C.byref(ctx)) == 0
+        live = []
+
+        def dev(host):
+            p = C.c_void_p()
+            assert lib.sc_malloc(ctx, max(host.nbytes, 4), C.byref(p)) == 0
+            assert lib.sc_memcpy_h2d(ctx, p, host.ctypes.data_as(C.c_void_p), host.nbytes) == 0
+            live.append(p)
+            return p
+
+        def empty(*shape, dtype=np.uint32):
+            return dev(np.zeros(shape, dtype=dtype))
+
+        def back(p, *shape, dtype=np.uint32):
+            out = np.zeros(shape, dtype=dtype)
+            assert lib.sc_memcpy_d2h(ctx, out.ctypes.data_as(C.c_void_p), p, out.nbytes) == 0
+            return out
+
+        def planes(rows, w):      # [l+1][B][w] bit-major from per-comparison lists
+            return np.stack([ints_to_words([rows[b][i] for b in range(B)], w) for i in range(l + 1)])
+
+        try:
+            keep = [words(sk.n, nw), words(sk.p, nw // 2), words(sk.q, nw // 2)]
+            a_key, b_key = C.c_int(), C.c_int()
+            assert lib.sc_paillier_key_create(ctx, keep[0][1], nw, None, None, 0, 0, C.byref(a_key)) == 0, lib.sc_last_error(ctx)
+            assert lib.sc_paillier_key_create(ctx, keep[0][1], nw, keep[1][1], keep[2][1], nw // 2, flags, C.byref(b_key)) == 0, lib.sc_last_error(ctx)
+            dk = [words(dgk.n, nd), words(dgk.g, nd), words(dgk.h, nd), words(dgk.u, ew), words(dgk.p, nd // 2), words(dgk.q, nd // 2),
+                  words(dgk.v_p, 5), words(dgk.v_q, 5)]
+            a_dgk, b_dgk = C.c_int(), C.c_int()
+            assert lib.sc_dgk_key_create(ctx, dk[0][1], dk[1][1], dk[2][1], nd, dk[3][1], ew, dgk.t, None, None, 0, None, None, 0, rbits, 8, 0,
+                                         None, -1, C.byref(a_dgk)) == 0, lib.sc_last_error(ctx)
+            assert lib.sc_dgk_key_create(ctx, dk[0][1], dk[1][1], dk[2][1], nd, dk[3][1], ew, dgk.t, dk[4][1], dk[5][1], nd // 2, dk[6][1], dk[7][1], 5,
+                                         rbits, 8, flags, None, -1, C.byref(b_dgk)) == 0, lib.sc_last_error(ctx)
+            # Alice: step 1 (+ randomization of [[z]])
+            d_x, d_y = dev(ints_to_words(x_enc, 2 * nw)), dev(ints_to_words(y_enc, 2 * nw))
+            d_r, d_rho_z = dev(ints_to_words([d.r for d in drs], nw)), dev(ints_to_words([d.rho_z for d in drs], nw))
+            d_z, d_alpha, d_alpha_t, d_rsmall, d_rshift = empty(B, 2 * nw), empty(B, dtype=np.uint64), empty(B, dtype=np.uint64), \
+                empty(B, dtype=np.uint64), empty(B, nw)
+            assert lib.sc_initiator_step1(ctx, a_key, l, d_x, d_y, d_r, d_rho_z, d_z, d_alpha, d_alpha_t, d_rsmall, d_rshift, B) == 0, lib.sc_last_error(ctx)
+            assert words_to_ints(back(d_z, B, 2 * nw)) == [t["z_enc"] for t in traces]
+            # Bob: steps 2, 4a, 4b (+ l + 1 randomizations)
+            d_rb = dev(planes([[d.r_d] + d.r_beta for d in drs], er))
+            d_zp, d_beta, d_dbit, d_z1, d_z2, d_db = empty(B, nw), empty(B, dtype=np.uint64), empty(B, dtype=np.uint64), empty(B, nw), \
+                empty(B, nw), empty(l + 1, B, nd)
+            assert lib.sc_keyholder_step2_4b(ctx, b_key, b_dgk, l, d_z, d_rb, er, d_zp, d_beta, d_dbit, d_z1, d_z2, d_db, B) == 0, lib.sc_last_error(ctx)
+            assert words_to_ints(back(d_zp, B, nw)) == [t["z"] for t in traces]
+            got_db = back(d_db, l + 1, B, nd)
+            assert words_to_ints(got_db[0]) == [t["d_sent"] for t in traces]
+            assert [words_to_ints(got_db[1:, b]) for b in range(B)] == [t["beta_enc"] for t in traces]
+            # Alice: steps 4c-4i (+ l + 1 randomizations, shuffle)
+            rc_pre = [[None] * (l + 1) for _ in range(B)]      # the oracle randomizes output k = c_{perm[k]} after the shuffle
+            for b, d in enumerate(drs):
+                for k, src in enumerate(d.perm):
+                    rc_pre[b][src] = d.r_c[k]
+            d_rhos, d_ra = dev(planes([d.rhos for d in drs], ew)), dev(planes(rc_pre, er))
+            d_perm = dev(np.array([d.perm for d in drs], dtype=np.int64))
+            d_da = dev(np.array([d.delta_a for d in drs], dtype=np.uint64))
+            d_c = empty(l + 1, B, nd)
+            beta_ptr = C.c_void_p(d_db.value + B * nd * 4)      # [beta_i] = planes 1.. of the same array: no copy inside
+            assert lib.sc_initiator_step4(ctx, a_dgk, l, d_db, beta_ptr, d_alpha, d_alpha_t, d_rsmall, d_da, d_rhos, ew, d_perm, d_ra, er, None,
+                                          d_c, B) == 0, lib.sc_last_error(ctx)
+            got_c = back(d_c, l + 1, B, nd)
+            assert [words_to_ints(got_c[:, b]) for b in range(B)] == [t["c_enc"] for t in traces]
+            # Bob: steps 4j, 5 (+ 3 randomizations)
+            d_rho3 = dev(np.concatenate([ints_to_words([getattr(d, f) for d in drs], nw) for f in ("rho_zeta1", "rho_zeta2", "rho_delta_b")]))
+            d_delta_b, d_out3 = empty(B, dtype=np.uint64), empty(3, B, 2 * nw)
+            assert lib.sc_keyholder_step4j_5(ctx, b_key, b_dgk, l, d_c, d_z1, d_z2, d_rho3, d_delta_b, d_out3, B) == 0, lib.sc_last_error(ctx)
+            assert back(d_delta_b, B, dtype=np.uint64).tolist() == [t["delta_b"] for t in traces]
+            # Alice: steps 6, 7
+            d_res = empty(B, 2 * nw)
+            z1p, z2p, dbp = d_out3, C.c_void_p(d_out3.value + B * 2 * nw * 4), C.c_void_p(d_out3.value + 2 * B * 2 * nw * 4)
+            assert lib.sc_initiator_step67(ctx, a_key, d_da, dbp, z1p, z2p, d_rsmall, d_rshift, d_res, B) == 0, lib.sc_last_error(ctx)
+            got = words_to_ints(back(d_res, B, 2 * nw))
+            assert got == expect and [sk.dec_raw(v) for v in got] == [int(x <= y) for x, y in zip(xs, ys)]
+            # the scheme objects' own operations: randomize, decrypt, encrypt bits, zero test -- one call each
+            d_m = dev(ints_to_words(xs, nw))
+            d_ct, d_rn, d_dec = empty(B, 2 * nw), empty(B, 2 * nw), empty(B, nw)
+            assert lib.sc_paillier_encrypt(ctx, a_key, d_m, nw, 0, d_ct, B) == 0
+            for key in (a_key, b_key):          # Alice's path (pairs modulo N) and the key holder's (CRT): identical integers
+                assert lib.sc_paillier_randomize(ctx, key, d_ct, d_rho_z, d_rn, B) == 0, lib.sc_last_error(ctx)
+                assert words_to_ints(back(d_rn, B, 2 * nw)) == [sk.randomize(sk.enc_raw(x), d.rho_z) for x, d in zip(xs, drs)]
+            assert lib.sc_paillier_decrypt(ctx, b_key, d_rn, d_dec, B) == 0 and words_to_ints(back(d_dec, B, nw)) == xs
+            assert lib.sc_paillier_decrypt(ctx, a_key, d_rn, d_dec, B) == -1 and b"secret" in lib.sc_last_error(ctx)
+            bits = np.array([i & 1 for i in range(B)], dtype=np.uint8)
+            d_bits, d_r1, d_e1, d_fl = dev(bits), dev(ints_to_words([d.r_d for d in drs], er)), empty(B, nd), empty(B, dtype=np.uint8)
+            for key in (a_dgk, b_dgk):
+                assert lib.sc_dgk_encrypt_bits_randomized(ctx, key, d_bits, d_r1, er, d_e1, B) == 0, lib.sc_last_error(ctx)
+                assert words_to_ints(back(d_e1, B, nd)) == [dgk.randomize(dgk.enc_raw(int(b)), d.r_d) for b, d in zip(bits, drs)]
+            assert lib.sc_dgk_is_zero(ctx, b_dgk, d_e1, d_fl, B) == 0 and back(d_fl, B, dtype=np.uint8).tolist() == [1 - (i & 1) for i in range(B)]
+            assert lib.sc_dgk_is_zero(ctx, a_dgk, d_e1, d_fl, B) == -1
+        finally:
+            for p in live:
+                lib.sc_free(ctx, p)
+            lib.sc_ctx_destroy(ctx)
