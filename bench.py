@@ -243,6 +243,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-shuffle", action="store_true", help="leave the step-4i permutation out (do_shuffle=False)")
     ap.add_argument("--streams", type=int, default=0, help="concurrent shards per GPU (one library context, HIP stream and host thread each); 1 = a single stream; "
                     "0 = automatic: 2 from 65536 comparisons per GPU")
+    ap.add_argument("--side-stream", type=int, default=-1, help="run the randomizer exponentiations of a step on a second library context and stream per shard, "
+                    "concurrently with the protocol's critical path (batch._AheadOfTime): 1 on, 0 off, -1 automatic (on below 65536 comparisons per GPU)")
     ap.add_argument("--latency-mode", type=int, default=1, help="small-batch kernel policy (sc_ctx_set_latency_mode): 0 never, 1 automatic, 2 always")
     ap.add_argument("--onelane-mode", type=int, default=1, help="large-batch kernel policy for the 1024-bit primes (sc_ctx_set_onelane_mode): 0 never, 1 automatic, 2 always")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -302,8 +304,10 @@ def main() -> None:
     eng = default_engine()
     ns = max(1, min(args.streams, B)) if args.streams > 0 else (2 if B >= 65536 else 1)
     ns = launcher.host_threads_per_rank(world, ns)      # shard threads of all ranks together stay within the node's cores
+    use_side = bool(args.side_stream) if args.side_stream >= 0 else (B < 65536)
     engines = [eng] + [Engine() for _ in range(1, ns)]
-    for e_ in engines:
+    side_engines = [Engine() for _ in range(ns)] if use_side else []
+    for e_ in engines + side_engines:
         e_.set_latency_mode(args.latency_mode)
         e_.set_onelane_mode(args.onelane_mode)
 
@@ -326,6 +330,17 @@ def main() -> None:
                 build_s = alice_d.table_build_s + bob_d.table_build_s
                 table_bytes = alice_d.table_bytes() + bob_d.table_bytes()
             sets.append(PartySet(alice_pai, alice_d, bob_p, bob_d, torch.cuda.Stream()))
+        for i, e_s in enumerate(side_engines):      # the second context of every shard: same keys, the first context's tables
+            bob_p = Paillier(p * q, p, q, engine=e_s, use_crt=use_crt)
+            bob_d = DGK(H("p") * H("q"), H("g"), H("h"), H("u"), dj["t"], H("p"), H("q"), H("v_p"), H("v_q"), engine=e_s,
+                        randomizer_bits=args.rbits, fixed_base_window=window, use_crt=use_crt)
+            alice_d = bob_d.public_copy()
+            bob_d.share_tables_from(sets[0].bob_dgk)
+            alice_d.share_tables_from(sets[0].alice_dgk)
+            alice_d.prepare(), bob_d.prepare()
+            alice_pai = bob_p.public_copy()
+            _ = bob_p.key, alice_pai.key
+            sets[i].side = PartySet(alice_pai, alice_d, bob_p, bob_d, torch.cuda.Stream())
         return sets, build_s, table_bytes
 
     parties, table_build_s, table_bytes = build_parties(args.fb_window)
@@ -345,7 +360,7 @@ def main() -> None:
         if ns == 1:
             ps = party_sets[0]
             return (lambda: secure_comparison_batch(x_enc, y_enc, l, ps.alice_paillier, ps.alice_dgk, ps.bob_paillier, ps.bob_dgk, draws,
-                                                    randomize=True)), (lambda: None)
+                                                    randomize=True, side=ps.side)), (lambda: None)
         runner = ConcurrentShards(party_sets)
         return (lambda: torch.cat(runner.run(shard_inputs, l, randomize=True), dim=0)), runner.close
 
@@ -398,9 +413,9 @@ def main() -> None:
         devices = ids.tolist()
         if rccl_ranks != world:
             raise SystemExit(f"bench.py: the all-reduce saw {rccl_ranks} ranks, expected {world}")
-    [e_.mac_counter(reset=True) for e_ in engines]
+    [e_.mac_counter(reset=True) for e_ in engines + side_engines]
     elapsed, res = timed(step, args.steps)
-    executed_macs = sum(e_.mac_counter() for e_ in engines)
+    executed_macs = sum(e_.mac_counter() for e_ in engines + side_engines)
     value = world * B * args.steps / elapsed
     if not all_correct(res):
         raise SystemExit("bench.py: decrypted results of the timed steps differ from x <= y")
@@ -475,7 +490,7 @@ def main() -> None:
             "config": {"workload": "batch %d comparisons per GPU, l=%d, %d-bit Paillier + %d-bit DGK (%s)" % (B, l, args.pbits, dbits, cfg_name),
                        "batch_per_gpu": B, "l": l, "paillier_bits": args.pbits, "dgk_bits": dbits, "dgk_key": dname, "dgk_randomizer_bits": args.rbits,
                        "fixed_base_window": args.fb_window, "keyholder_crt": use_crt, "shuffle_4i": not args.no_shuffle,
-                       "parallelism": "shard%d" % world, "streams_per_gpu": ns,
+                       "parallelism": "shard%d" % world, "streams_per_gpu": ns, "randomizers_on_side_stream": use_side,
                        "fixed_base_table_bytes": table_bytes, "table_build_s": table_build_s,
                        "table_note": "device bytes of Alice's table for h mod n plus the key holder's CRT tables for h mod p, h mod q, built once per GPU "
                                      "(untimed set-up, SURVEY 8(d)) and shared read-only by the %d shard context(s)" % ns},

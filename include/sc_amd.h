@@ -206,6 +206,12 @@ int sc_dgk_step4(sc_ctx* ctx, int mod, int cst_g, int cst_ginv, int l, const uin
  * device arrays of canonical words; N has `nwords` words, ciphertexts 2 * nwords; DGK residues `nwords` of its key. */
 #define SC_KEY_NO_CRT 1
 #define SC_KEY_NO_PAIRS 2
+/* `flags` of the step entry points below.  SC_STEP_RANDOMIZERS_READY: the randomizer argument (rho_z / r_rand / rho3) holds the
+ * FINISHED randomizers -- rho^N mod N^2 as [..][2 nwords(N)], h^r mod n as [..][nwords(n)] -- computed ahead of time by
+ * sc_paillier_randomize / sc_dgk_randomize with c = NULL, e.g. on a second context and stream while the protocol's critical
+ * path runs (the reference pre-generates its randomizers in background workers: boot_randomness_generation,
+ * SC/initiator.py:205-210, SC/keyholder.py:174-179).  The step then applies them with one modular product each. */
+#define SC_STEP_RANDOMIZERS_READY 1
 int sc_paillier_key_create(sc_ctx* ctx, const uint32_t* n_hptr, int nwords, const uint32_t* p_hptr /* nullable */,
                            const uint32_t* q_hptr /* nullable */, int pwords, int flags, int* out_key);
 /* the primitive handles behind a key (for callers that mix scheme-level and primitive calls) */
@@ -245,13 +251,13 @@ int sc_dgk_any_zero(sc_ctx* ctx, int key, const uint32_t* c_dptr, int planes, ui
  * z = [[y]] [[x]]^-1 [[2^l + r]] mod N^2, randomized with rho_z^N when rho_z is given (:109); alpha = r mod 2^l,
  * alpha_tilde = (r - N) mod 2^l, rsmall = [r < (N-1)/2] (uint64 each), rshift = r div 2^l ([count][nwords]). */
 int sc_initiator_step1(sc_ctx* ctx, int paillier_key, int l, const uint32_t* x_enc_dptr, const uint32_t* y_enc_dptr,
-                       const uint32_t* r_dptr, const uint32_t* rho_z_dptr /* nullable */, uint32_t* z_out_dptr, uint64_t* alpha_dptr,
+                       const uint32_t* r_dptr, const uint32_t* rho_z_dptr /* nullable */, int flags, uint32_t* z_out_dptr, uint64_t* alpha_dptr,
                        uint64_t* alpha_tilde_dptr, uint64_t* rsmall_dptr, uint32_t* rshift_dptr, uint64_t count);
 /* KeyHolder.step_2 + step_4a + step_4b (+ the l + 1 .randomize() of SC/keyholder.py:106-108 when r_rand is given): decrypt z,
  * derive beta / d / zeta_1 / zeta_2, and encrypt d and the bits of beta bit-major: d_beta_out[l+1][count][nwords(n)], plane 0 =
  * [d], plane 1 + i = [beta_i].  z_out: [count][nwords(N)]; beta / dbit uint64. */
 int sc_keyholder_step2_4b(sc_ctx* ctx, int paillier_key, int dgk_key, int l, const uint32_t* z_enc_dptr,
-                          const uint32_t* r_rand_dptr /* nullable */, int r_words, uint32_t* z_out_dptr, uint64_t* beta_dptr,
+                          const uint32_t* r_rand_dptr /* nullable */, int r_words, int flags, uint32_t* z_out_dptr, uint64_t* beta_dptr,
                           uint64_t* dbit_dptr, uint32_t* zeta1_dptr, uint32_t* zeta2_dptr, uint32_t* d_beta_out_dptr, uint64_t count);
 /* Initiator.step_4c .. step_4i for a batch (SC/initiator.py:272-516): one inversion pass over [d], [beta_i], the fused steps
  * 4c-4h (sc_dgk_step4), then -- when rhos is given -- the blinding c_i^rho_i (:512), the re-randomization * h^r_i when r_rand is
@@ -261,17 +267,17 @@ int sc_keyholder_step2_4b(sc_ctx* ctx, int paillier_key, int dgk_key, int l, con
 int sc_initiator_step4(sc_ctx* ctx, int dgk_key, int l, const uint32_t* d_enc_dptr, const uint32_t* beta_enc_dptr,
                        const uint64_t* alpha_dptr, const uint64_t* alpha_tilde_dptr, const uint64_t* rsmall_dptr,
                        const uint64_t* delta_a_dptr, const uint32_t* rhos_dptr /* nullable */, int rho_words,
-                       const int64_t* permutation_dptr /* nullable */, const uint32_t* r_rand_dptr /* nullable */, int r_words,
+                       const int64_t* permutation_dptr /* nullable */, const uint32_t* r_rand_dptr /* nullable */, int r_words, int flags,
                        uint32_t* c_unblinded_out_dptr /* nullable */, uint32_t* c_out_dptr, uint64_t count);
 /* Step 4i on its own (blinding, optional re-randomization, optional shuffle) for a vector c_in[l+1][count][nwords] that is already
  * there (SC/initiator.py:487-516, :153-154); c_out must not be c_in when a permutation is given. */
 int sc_initiator_step4i(sc_ctx* ctx, int dgk_key, int l, const uint32_t* c_in_dptr, const uint32_t* rhos_dptr, int rho_words,
-                        const int64_t* permutation_dptr /* nullable */, const uint32_t* r_rand_dptr /* nullable */, int r_words,
+                        const int64_t* permutation_dptr /* nullable */, const uint32_t* r_rand_dptr /* nullable */, int r_words, int flags,
                         uint32_t* c_out_dptr, uint64_t count);
 /* KeyHolder.step_4j + step_5 (+ the 3 .randomize() of SC/keyholder.py:126-128 when rho3 is given): delta_B per comparison,
  * then out3[3][count][2 nwords] = [[zeta_1]], [[zeta_2]], [[delta_B]]; rho3: [3][count][nwords] in the same order. */
 int sc_keyholder_step4j_5(sc_ctx* ctx, int paillier_key, int dgk_key, int l, const uint32_t* c_enc_dptr, const uint32_t* zeta1_dptr,
-                          const uint32_t* zeta2_dptr, const uint32_t* rho3_dptr /* nullable */, uint64_t* delta_b_out_dptr,
+                          const uint32_t* zeta2_dptr, const uint32_t* rho3_dptr /* nullable */, int flags, uint64_t* delta_b_out_dptr,
                           uint32_t* out3_dptr, uint64_t count);
 /* Initiator.step_6 + step_7 (SC/initiator.py:518-564) with one inversion pass: out = [[x <= y]], not randomized. */
 int sc_initiator_step67(sc_ctx* ctx, int paillier_key, const uint64_t* delta_a_dptr, const uint32_t* delta_b_enc_dptr,

@@ -93,11 +93,11 @@ def load() -> C.CDLL:
         "sc_dgk_encrypt_bits_randomized": (i32, [vp, i32, vp, vp, i32, vp, u64]),
         "sc_dgk_is_zero": (i32, [vp, i32, vp, vp, u64]),
         "sc_dgk_any_zero": (i32, [vp, i32, vp, i32, u64, vp]),
-        "sc_initiator_step1": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64]),
-        "sc_keyholder_step2_4b": (i32, [vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, u64]),
-        "sc_initiator_step4": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, u64]),
-        "sc_initiator_step4i": (i32, [vp, i32, i32, vp, vp, i32, vp, vp, i32, vp, u64]),
-        "sc_keyholder_step4j_5": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, u64]),
+        "sc_initiator_step1": (i32, [vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, u64]),
+        "sc_keyholder_step2_4b": (i32, [vp, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, u64]),
+        "sc_initiator_step4": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, u64]),
+        "sc_initiator_step4i": (i32, [vp, i32, i32, vp, vp, i32, vp, vp, i32, i32, vp, u64]),
+        "sc_keyholder_step4j_5": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, u64]),
         "sc_initiator_step67": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, u64]),
         "sc_rng_seed": (i32, [vp, vp]),
         "sc_rng_bits": (i32, [vp, i32, vp, u64]),

@@ -84,16 +84,73 @@ def boot_pools(count: int, l: int, alice_paillier: Paillier, alice_dgk: DGK, bob
     bob_dgk.boot_randomness_generation_batch((l + 1) * count, source, generator)
 
 
+class _AheadOfTime:
+    """The 4 + 2(l+1) randomizer exponentiations of a batch -- 60 % of its multiply-adds, and functions of the draws alone --
+    queued on a SECOND library context and stream while the protocol's critical path runs on the caller's: the reference
+    pre-generates its randomizers in background workers the same way (boot_randomness_generation, SC/initiator.py:205-210,
+    SC/keyholder.py:174-179).  Every job records an event; the step that consumes a randomizer waits for it on the main stream
+    and applies it with one modular product (SC_STEP_RANDOMIZERS_READY).  Same residues as the fused launches."""
+
+    def __init__(self, side: "PartySet", draws: BatchDraws, l: int) -> None:
+        count = draws.r.shape[0]
+        jobs = (("rz", lambda: side.alice_paillier.randomizer_batch(draws.rho_z)),                       # needed first
+                ("hr_bob", lambda: side.bob_dgk.randomize_batch(None, draws.r_bob_dgk.reshape((l + 1) * count, -1))),
+                ("hr_alice", lambda: side.alice_dgk.randomize_batch(None, draws.r_alice_dgk.reshape((l + 1) * count, -1))),
+                ("r3", lambda: side.bob_paillier.randomizer_batch(cat_rows([draws.rho_zeta_1, draws.rho_zeta_2, draws.rho_delta_b]))))
+        self._out = {}
+        self.main = None
+        if not draws.r.is_cuda:                    # host tensors (the CPU test tier's stand-in engine): nothing to overlap
+            for name, fn in jobs:
+                self._out[name] = (fn(), None)
+            return
+        self.main = torch.cuda.current_stream(draws.r.device)
+        with torch.cuda.stream(side.stream):
+            side.stream.wait_stream(self.main)     # the draws were produced on the caller's stream
+            for name, fn in jobs:
+                t = fn()
+                t.record_stream(self.main)         # allocated on the side stream, consumed on the main one
+                ev = torch.cuda.Event()
+                ev.record(side.stream)
+                self._out[name] = (t, ev)
+
+    def take(self, name: str) -> torch.Tensor:
+        t, ev = self._out.pop(name)
+        if ev is not None:
+            self.main.wait_event(ev)
+        return t
+
+
 def secure_comparison_batch(x_enc: torch.Tensor, y_enc: torch.Tensor, l: int, alice_paillier: Paillier, alice_dgk: DGK,
                             bob_paillier: Paillier, bob_dgk: DGK, draws: BatchDraws, randomize: bool | str = True,
-                            trace: BatchTrace | None = None) -> torch.Tensor:
+                            trace: BatchTrace | None = None, side: "PartySet | None" = None) -> torch.Tensor:
     """[[x <= y]] for B comparisons.  x_enc, y_enc: [B][2nw] Paillier ciphertexts under Bob's key.
     randomize: True = every `.randomize()` of the interactive protocol, computed from the injected randomizer inputs in `draws`;
     "pool" = the same randomizations with pre-generated randomizers from the schemes' device pools (boot_pools), i.e. the
     online phase of a deployment that generates randomness ahead of time like the reference's background workers;
-    False = the static step chain without randomization."""
+    False = the static step chain without randomization.
+    side: both parties' scheme objects bound to a SECOND engine and stream (same keys): with randomize=True the randomizer
+    exponentiations run there, concurrently with the critical path on the caller's stream (see _AheadOfTime) -- inside this
+    call, so they are part of the step; identical results."""
     if randomize == "pool":
         return _secure_comparison_batch_pooled(x_enc, y_enc, l, alice_paillier, alice_dgk, bob_paillier, bob_dgk, draws)
+    if side is not None and randomize:
+        ahead = _AheadOfTime(side, draws, l)
+        count = x_enc.shape[0]
+        z_enc, a_plain = Initiator.step_1_batch(x_enc, y_enc, l, alice_paillier, draws.r, None)
+        z_enc = alice_paillier.add_batch(z_enc, ahead.take("rz"))
+        b_plain, d_enc, beta_enc = KeyHolder.step_2_4b_batch(z_enc, l, bob_paillier, bob_dgk,
+                                                             ahead.take("hr_bob").reshape(l + 1, count, -1), randomizers_ready=True)
+        c_sent, c_h = Initiator.step_4_batch(d_enc, beta_enc, a_plain, draws.delta_a, alice_dgk, draws.rhos, draws.permutation,
+                                             ahead.take("hr_alice").reshape(l + 1, count, -1), want_unblinded=trace is not None,
+                                             randomizers_ready=True)
+        delta_b, zeta_1_enc, zeta_2_enc, delta_b_enc = KeyHolder.step_4j_5_batch(c_sent, b_plain, bob_paillier, bob_dgk, ahead.take("r3"),
+                                                                                 randomizers_ready=True)
+        result = Initiator.step_6_7_batch(draws.delta_a, delta_b_enc, zeta_1_enc, zeta_2_enc, a_plain, l, alice_paillier)
+        if trace is not None:
+            trace.z_enc, trace.z, trace.d_enc, trace.beta_enc = z_enc, b_plain.z, d_enc, beta_enc
+            trace.c_step4h, trace.c_sent, trace.delta_b = c_h, c_sent, delta_b
+            trace.zeta_1_enc, trace.zeta_2_enc, trace.delta_b_enc = zeta_1_enc, zeta_2_enc, delta_b_enc
+        return result
     # five library calls per batch (include/sc_amd.h, scheme-level entry points)
     # Alice: steps 1, 3 (+ the randomization of [[z]])
     z_enc, a_plain = Initiator.step_1_batch(x_enc, y_enc, l, alice_paillier, draws.r, draws.rho_z if randomize else None)
@@ -147,6 +204,7 @@ class PartySet:
     bob_paillier: Paillier
     bob_dgk: DGK
     stream: "torch.cuda.Stream"
+    side: "PartySet | None" = None      # a second context + stream for the randomizer exponentiations (secure_comparison_batch)
 
 
 def split_draws(draws: BatchDraws, bounds: list[tuple[int, int]]) -> list[BatchDraws]:
@@ -201,7 +259,7 @@ class ConcurrentShards:
             with torch.cuda.device(device), torch.cuda.stream(p.stream):
                 p.stream.wait_stream(caller)          # the inputs were produced on the caller's stream
                 res = secure_comparison_batch(shard[0], shard[1], l, p.alice_paillier, p.alice_dgk, p.bob_paillier, p.bob_dgk,
-                                              shard[2], randomize)
+                                              shard[2], randomize, side=p.side)
                 res.record_stream(caller)             # the caller consumes it on its own stream
                 return res
 

@@ -923,8 +923,11 @@ int sc_fixedbase_pow(sc_ctx* ctx, int fbt, const uint32_t* e, int ewords, const 
   return run_vm(ctx, f.mod, it->second, ex, 3, count, f.d_rows);
 }
 
+// premul (nullable): a finished factor per item (e.g. a randomizer h^r computed ahead of time on another stream) multiplied in
+// before the store -- the alternative to the fixed-base tail (fbt / e2)
 static int modexp_var_impl(sc_ctx* ctx, int mod, const uint32_t* x, const uint32_t* e, int ewords, int ebits, int fbt,
-                           const uint32_t* e2, int e2words, const uint64_t* dest, uint32_t* out, uint64_t count) {
+                           const uint32_t* e2, int e2words, const uint64_t* dest, uint32_t* out, uint64_t count,
+                           const uint32_t* premul = nullptr) {
   if (ctx && count == 0) return SC_OK;  // empty batch: nothing to do (pointers may be null)
   if (!valid_mod(ctx, mod) || !x || !e || !out || ewords <= 0 || ebits <= 0 || ebits > 32 * ewords)
     return fail(ctx, SC_ERR_ARG, "sc_modexp_var: bad argument");
@@ -934,7 +937,7 @@ static int modexp_var_impl(sc_ctx* ctx, int mod, const uint32_t* x, const uint32
     if (fbt >= (int)ctx->fbts.size() || ctx->fbts[fbt].mod != mod || !e2 || e2words <= 0) return fail(ctx, SC_ERR_ARG, "sc_modexp_var: bad fixed-base table");
     f = &ctx->fbts[fbt];
   }
-  std::string key = "mvar:" + std::to_string(mod) + ":" + std::to_string(ebits) + ":" + std::to_string(fbt) + (dest ? ":s" : "");
+  std::string key = "mvar:" + std::to_string(mod) + ":" + std::to_string(ebits) + ":" + std::to_string(fbt) + (dest ? ":s" : "") + (premul ? ":p" : "");
   auto it = ctx->progs.find(key);
   if (it == ctx->progs.end()) {
     const int w = ebits <= 4 ? 1 : (ebits <= 12 ? 2 : 3);
@@ -946,16 +949,16 @@ static int modexp_var_impl(sc_ctx* ctx, int mod, const uint32_t* x, const uint32
     bd.loadt_tbldig(1, (nd - 1) * w, w, 0);
     for (int d = nd - 2; d >= 0; d--) { for (int k = 0; k < w; k++) bd.sqr(); bd.mul_tbldig(1, d * w, w, 0); }
     if (f) for (int j = 0; j < f->nwin; j++) bd.mul_fbt(3, j * f->window, f->window, j);
-    bd.redc();
+    if (premul) bd.mul_extw(5); else bd.redc();          // (x^e R) * premul / R = x^e premul: leaves Montgomery form by itself
     if (dest) bd.storew_at(2, 4); else bd.storew(2);
     bd.end();
     Prog p; int rc = finalize_prog(ctx, m, bd, &p); if (rc) return rc;
     it = ctx->progs.emplace(key, p).first;
   }
   // a scattered store never leaves the output array: rows >= count are dropped by the limit of the output operand
-  VmExt ex[5] = {mk_ext(x, m.nwords, m.nwords), mk_ext(e, ewords, ewords), mk_ext(out, m.nwords, m.nwords, dest ? count : ~0ull),
-                 mk_ext(e2, e2words, e2words), mk_ext(dest, 2, 2)};
-  return run_vm(ctx, mod, it->second, ex, 5, count, f ? f->d_rows : nullptr);
+  VmExt ex[6] = {mk_ext(x, m.nwords, m.nwords), mk_ext(e, ewords, ewords), mk_ext(out, m.nwords, m.nwords, dest ? count : ~0ull),
+                 mk_ext(e2, e2words, e2words), mk_ext(dest, 2, 2), mk_ext(premul, m.nwords, m.nwords)};
+  return run_vm(ctx, mod, it->second, ex, 6, count, f ? f->d_rows : nullptr);
 }
 
 int sc_modexp_var(sc_ctx* ctx, int mod, const uint32_t* x, const uint32_t* e, int ewords, int ebits, int fbt,
@@ -1165,6 +1168,7 @@ int sc_modinv(sc_ctx* ctx, int mod, const uint32_t* x, uint32_t* out, uint64_t c
   int64_t bad = -1;
   for (uint64_t i = 0; i < pend.top_count && bad < 0; i++) if (st[i] != 1) bad = (int64_t)i;
   if (bad < 0) return SC_OK;
+  if (st[bad] == 2) return fail(ctx, SC_ERR_HIP, "sc_modinv: the inversion kernel left its proven value range (internal error)");
   // error path: `bad` indexes the deepest level's chunk products; walk back up, one member test per level
   const Mod& m = ctx->mods[mod];
   for (int lv = (int)pend.levels.size() - 1; lv >= 0; lv--) {

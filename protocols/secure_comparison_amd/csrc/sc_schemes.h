@@ -426,8 +426,8 @@ int sc_dgk_any_zero(sc_ctx* ctx, int key, const uint32_t* c, int planes, uint64_
 
 // ---- protocol steps ----------------------------------------------------------------------------------------------------------
 int sc_initiator_step1(sc_ctx* ctx, int paillier_key_id, int l, const uint32_t* x_enc, const uint32_t* y_enc, const uint32_t* r,
-                       const uint32_t* rho_z, uint32_t* z_out, uint64_t* alpha, uint64_t* alpha_tilde, uint64_t* rsmall, uint32_t* rshift,
-                       uint64_t count) {
+                       const uint32_t* rho_z, int flags, uint32_t* z_out, uint64_t* alpha, uint64_t* alpha_tilde, uint64_t* rsmall,
+                       uint32_t* rshift, uint64_t count) {
   if (ctx && count == 0) return SC_OK;
   const PaillierKey* kp = paillier_key(ctx, paillier_key_id);
   if (!kp || !x_enc || !y_enc || !r || !z_out || !alpha || !alpha_tilde || !rsmall || !rshift || l <= 0 || l > 64)
@@ -445,20 +445,25 @@ int sc_initiator_step1(sc_ctx* ctx, int paillier_key_id, int l, const uint32_t* 
   rc = sc_paillier_encrypt_raw(ctx, k.mod_n2, k.cst_n, m1, k.nw + 1, xinv, count); if (rc) return rc;                // [[2^l + r]]
   if (!rho_z) return sc_modmul(ctx, k.mod_n2, t, 2 * k.nw, xinv, 2 * k.nw, z_out, count);
   rc = sc_modmul(ctx, k.mod_n2, t, 2 * k.nw, xinv, 2 * k.nw, t, count); if (rc) return rc;
+  if (flags & SC_STEP_RANDOMIZERS_READY) return sc_modmul(ctx, k.mod_n2, t, 2 * k.nw, rho_z, 2 * k.nw, z_out, count);   // rho_z^N computed ahead
   return sc_paillier_randomize(ctx, paillier_key_id, t, rho_z, z_out, count);                                         // .randomize() (:109)
 }
 
 int sc_initiator_step4i(sc_ctx* ctx, int dgk_key_id, int l, const uint32_t* c_in, const uint32_t* rhos, int rho_words, const int64_t* permutation,
-                        const uint32_t* r_rand, int r_words, uint32_t* c_out, uint64_t count) {
+                        const uint32_t* r_rand, int r_words, int flags, uint32_t* c_out, uint64_t count) {
   if (ctx && count == 0) return SC_OK;
   const DgkKey* kp = dgk_key(ctx, dgk_key_id);
   if (!kp || l <= 0 || l > 64 || !c_in || !rhos || rho_words <= 0 || !c_out || (r_rand && r_words <= 0))
     return fail(ctx, SC_ERR_ARG, "sc_initiator_step4i: bad argument");
   const DgkKey k = *kp;
-  if (r_rand && k.fbt_h < 0) return fail(ctx, SC_ERR_ARG, "sc_initiator_step4i: this key has no table for h modulo n (key holder with CRT)");
+  const bool ready = r_rand && (flags & SC_STEP_RANDOMIZERS_READY);     // r_rand holds h^r itself ([l+1][count][nwords]), computed ahead
+  if (r_rand && !ready && k.fbt_h < 0) return fail(ctx, SC_ERR_ARG, "sc_initiator_step4i: this key has no table for h modulo n (key holder with CRT)");
   const uint64_t planes = (uint64_t)l + 1, items = planes * count;
   const int ubits = big_bits(big_sub_small(k.u, 1));
-  if (!permutation) return sc_modexp_var(ctx, k.mod_n, c_in, rhos, rho_words, ubits, r_rand ? k.fbt_h : -1, r_rand, r_words, c_out, items);
+  const int fbt = (r_rand && !ready) ? k.fbt_h : -1;
+  const uint32_t* e2 = ready ? nullptr : r_rand;
+  const uint32_t* premul = ready ? r_rand : nullptr;
+  if (!permutation) return modexp_var_impl(ctx, k.mod_n, c_in, rhos, rho_words, ubits, fbt, e2, r_words, nullptr, c_out, items, premul);
   if (c_in == c_out) return fail(ctx, SC_ERR_ARG, "sc_initiator_step4i: a shuffled store cannot work in place");
   uint64_t* dest;
   int rc = tmp_words(ctx, TMP_S_H, items, &dest); if (rc) return rc;
@@ -467,12 +472,12 @@ int sc_initiator_step4i(sc_ctx* ctx, int dgk_key_id, int l, const uint32_t* c_in
   HIPCHK(ctx, hipMemsetAsync(dest, 0xff, items * 8, ctx->stream));
   hipLaunchKernelGGL(k_perm_to_dest, dim3(blocks_for(count)), dim3(256), 0, ctx->stream, permutation, dest, (int)planes, count);
   HIPCHK(ctx, hipGetLastError());
-  return sc_modexp_var_scatter(ctx, k.mod_n, c_in, rhos, rho_words, ubits, r_rand ? k.fbt_h : -1, r_rand, r_words, dest, c_out, items);
+  return modexp_var_impl(ctx, k.mod_n, c_in, rhos, rho_words, ubits, fbt, e2, r_words, dest, c_out, items, premul);
 }
 
 int sc_initiator_step4(sc_ctx* ctx, int dgk_key_id, int l, const uint32_t* d_enc, const uint32_t* beta_enc, const uint64_t* alpha,
                        const uint64_t* alpha_tilde, const uint64_t* rsmall, const uint64_t* delta_a, const uint32_t* rhos, int rho_words,
-                       const int64_t* permutation, const uint32_t* r_rand, int r_words, uint32_t* c_unblinded_out, uint32_t* c_out,
+                       const int64_t* permutation, const uint32_t* r_rand, int r_words, int flags, uint32_t* c_unblinded_out, uint32_t* c_out,
                        uint64_t count) {
   if (ctx && count == 0) return SC_OK;
   const DgkKey* kp = dgk_key(ctx, dgk_key_id);
@@ -500,11 +505,11 @@ int sc_initiator_step4(sc_ctx* ctx, int dgk_key_id, int l, const uint32_t* d_enc
   else if (!c_h) { rc = tmp_words(ctx, TMP_S_G, items * row, &c_h); if (rc) return rc; }
   rc = sc_dgk_step4(ctx, k.mod_n, k.cst_g, k.cst_ginv, l, beta_enc, inv + count * row, d_enc, inv, alpha, alpha_tilde, rsmall, delta_a, c_h, count);
   if (rc || !rhos) return rc;
-  return sc_initiator_step4i(ctx, dgk_key_id, l, c_h, rhos, rho_words, permutation, r_rand, r_words, c_out, count);
+  return sc_initiator_step4i(ctx, dgk_key_id, l, c_h, rhos, rho_words, permutation, r_rand, r_words, flags, c_out, count);
 }
 
 int sc_keyholder_step2_4b(sc_ctx* ctx, int paillier_key_id, int dgk_key_id, int l, const uint32_t* z_enc, const uint32_t* r_rand, int r_words,
-                          uint32_t* z_out, uint64_t* beta, uint64_t* dbit, uint32_t* zeta1, uint32_t* zeta2, uint32_t* d_beta_out, uint64_t count) {
+                          int flags, uint32_t* z_out, uint64_t* beta, uint64_t* dbit, uint32_t* zeta1, uint32_t* zeta2, uint32_t* d_beta_out, uint64_t count) {
   if (ctx && count == 0) return SC_OK;
   const PaillierKey* pk = paillier_key(ctx, paillier_key_id);
   const DgkKey* dk = dgk_key(ctx, dgk_key_id);
@@ -519,6 +524,8 @@ int sc_keyholder_step2_4b(sc_ctx* ctx, int paillier_key_id, int dgk_key_id, int 
   rc = tmp_words(ctx, TMP_S_I, items, &bits); if (rc) return rc;
   hipLaunchKernelGGL(k_bob_bits, dim3(blocks_for(items)), dim3(256), 0, ctx->stream, dbit, beta, bits, l, count);
   HIPCHK(ctx, hipGetLastError());
+  if (r_rand && (flags & SC_STEP_RANDOMIZERS_READY))        // r_rand holds h^r itself: g^bit * h^r is one selected-constant product
+    return sc_modmul_const_sel(ctx, d.mod_n, r_rand, -1, d.cst_g, bits, d_beta_out, items);
   if (r_rand) return dgk_randomize_impl(ctx, d, nullptr, bits, r_rand, r_words, d_beta_out, items);
   // unrandomized: g^bit -- the residue 1 times (1 or g), chosen per item inside the launch
   std::string key = "bits1:" + std::to_string(d.mod_n) + ":" + std::to_string(d.cst_g);
@@ -536,7 +543,7 @@ int sc_keyholder_step2_4b(sc_ctx* ctx, int paillier_key_id, int dgk_key_id, int 
 }
 
 int sc_keyholder_step4j_5(sc_ctx* ctx, int paillier_key_id, int dgk_key_id, int l, const uint32_t* c_enc, const uint32_t* zeta1,
-                          const uint32_t* zeta2, const uint32_t* rho3, uint64_t* delta_b_out, uint32_t* out3, uint64_t count) {
+                          const uint32_t* zeta2, const uint32_t* rho3, int flags, uint64_t* delta_b_out, uint32_t* out3, uint64_t count) {
   if (ctx && count == 0) return SC_OK;
   const PaillierKey* pk = paillier_key(ctx, paillier_key_id);
   const DgkKey* dk = dgk_key(ctx, dgk_key_id);
@@ -554,6 +561,7 @@ int sc_keyholder_step4j_5(sc_ctx* ctx, int paillier_key_id, int dgk_key_id, int 
   uint32_t* enc;
   rc = tmp_words(ctx, TMP_S_F, 3 * count * 2 * p.nw, &enc); if (rc) return rc;
   rc = sc_paillier_encrypt_raw(ctx, p.mod_n2, p.cst_n, m3, p.nw, enc, 3 * count); if (rc) return rc;
+  if (flags & SC_STEP_RANDOMIZERS_READY) return sc_modmul(ctx, p.mod_n2, enc, 2 * p.nw, rho3, 2 * p.nw, out3, 3 * count);   // rho^N computed ahead
   return sc_paillier_randomize(ctx, paillier_key_id, enc, rho3, out3, 3 * count);                                    // the 3 .randomize() (:126-128)
 }
 

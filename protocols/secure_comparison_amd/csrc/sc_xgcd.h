@@ -106,9 +106,20 @@ struct MW {
 //                (f, g) <- (u f + v g, q f + r g) / 2^30                       (exact)
 //                (d, e) <- (u d + v e + md n, q d + r e + me n) / 2^30         (md, me in (-2^30, 0] make the sums divisible)
 // The multiword numbers are kept REDUNDANTLY: lane L holds a signed value x_L of WPL words plus a signed overflow word, the
-// number is sum x_L 2^(32 WPL L).  A round is then lane-local (the matrix is applied to every lane's value on its own; only the
-// 30 bits shifted out of a lane travel to the lane below, one DPP move per number), there is no carry propagation across lanes
-// until the very end, and |x_L| stays below 2^(32 WPL + 1) in practice (the bound |d| <= (rounds + 1) n holds for the value).
+// number is sum x_L B^L with B = 2^(32 WPL).  A round is then lane-local (the matrix is applied to every lane's value on its own;
+// only the 30 bits shifted out of a lane travel to the lane below, one DPP move per number) and there is no carry propagation
+// across lanes until the very end.
+// PROVEN bound on the lane values (oracle/xgcd_model.py restates the kernel and tests/test_xgcd_model_cpu.py drives it with
+// adversarial matrices and inputs).  The transition matrix of k division steps is a product of the per-step matrices
+// (0 2; -1 1), (2 0; 1 1), (2 0; 0 1), whose rows have absolute sums <= 2, so |u| + |v| <= 2^30 and |q| + |r| <= 2^30 for a
+// round.  With M_t = max_L |x_L| after t rounds:  |u f_L + v g_L| <= 2^30 M_t, its quotient by 2^30 is at most M_t + 1 in
+// magnitude, and the 30 bits arriving from the lane above add a value in [0, B):   M_(t+1) <= M_t + B + 1  for f, g.
+// For d, e the multiple m n_L (|m| < 2^30, 0 <= n_L < B) adds at most B more:       M_(t+1) <= M_t + 2 B + 1.
+// Growth is ADDITIVE, not a bit per round: from M_0 < B,  M_t < (t + 1)(2 B + 1) -- below 2^11 B for the 788 rounds of the
+// largest operand (8192 bits), against the 2^31 B the signed overflow word can hold.  The 64-bit partial sums of apply() stay
+// below 2^63 for the same reason ((2^31 - 1)(2^32 - 1) + 2^31 < 2^63).  The kernel checks the bound it relies on (|overflow
+// word| < 2^24 in every lane after the last round) and reports status 2 instead of a result if it were ever violated.
+// The value-level bound |d| <= (rounds + 1) n holds as well.
 // The round count is the proven bound for the operand size (no zero test on a redundant g is needed: once g = 0 further steps
 // leave f unchanged and d congruent).  4096-bit residues: 394 rounds of ~250 vector + ~350 scalar instructions instead of
 // ~8200 iterations of multiword shift / add / compare with a ballot carry look-ahead each.
@@ -246,6 +257,14 @@ __global__ void __launch_bounds__(64) k_xgcd(const uint32_t* __restrict__ xin, u
 #pragma unroll
     for (int k = 0; k < NW; k++) { f[k] = nf[k]; g[k] = ng[k]; d[k] = nd[k]; e[k] = ne[k]; }
   }
+  // the bound the redundant form relies on (see the header): overflow words far below 2^31
+  bool bound_ok;
+  {
+    const int32_t lim = 1 << 24;
+    const int32_t of = (int32_t)f[WPL], og = (int32_t)g[WPL], od = (int32_t)d[WPL], oe = (int32_t)e[WPL];
+    const bool bad = of >= lim || of <= -lim || og >= lim || og <= -lim || od >= lim || od <= -lim || oe >= lim || oe <= -lim;
+    bound_ok = __ballot(bad) == 0;
+  }
   D::normalize(f);
   D::normalize(g);
   D::normalize(d);
@@ -257,7 +276,7 @@ __global__ void __launch_bounds__(64) k_xgcd(const uint32_t* __restrict__ xin, u
 #pragma unroll
   for (int k = 0; k < WPL; k++) allones &= fw[k];
   const bool f_is_one = M::is_one(fw), f_is_minus_one = __ballot(allones != 0xffffffffu) == 0;
-  const bool ok = M::is_zero(gw) && (f_is_one || f_is_minus_one);
+  const bool ok = bound_ok && M::is_zero(gw) && (f_is_one || f_is_minus_one);
   if (f_is_minus_one) {   // x^-1 = -d
     uint32_t t[WPL];
 #pragma unroll
@@ -283,7 +302,7 @@ __global__ void __launch_bounds__(64) k_xgcd(const uint32_t* __restrict__ xin, u
       if (i < nw) out[item * nw + i] = dw[k];
     }
   }
-  if (lane == 0) status[item] = ok ? 1 : 0;
+  if (lane == 0) status[item] = ok ? 1 : (bound_ok ? 0 : 2);      // 2: internal bound violated (never expected; reported as an error)
   (void)zero;
 }
 

@@ -601,51 +601,53 @@ class Engine:
                 raise ValueError(f"{name}: {t.numel()} items, expected {count}")
 
     def initiator_step1(self, key: PaillierKey, l: int, x_enc: torch.Tensor, y_enc: torch.Tensor, r: torch.Tensor,
-                        rho_z: torch.Tensor | None = None):
-        """(z_enc, alpha, alpha_tilde, r_small, r_shift): Initiator.step_1 / step_3 for a batch, [[z]] randomized with rho_z^N."""
+                        rho_z: torch.Tensor | None = None, ready: bool = False):
+        """(z_enc, alpha, alpha_tilde, r_small, r_shift): Initiator.step_1 / step_3 for a batch, [[z]] randomized with rho_z^N
+        (`ready`: rho_z holds the finished randomizers rho_z^N mod N^2, [B][2nw], computed ahead of time)."""
         count = self._items(x_enc)
         nw = key.mod_n.nwords
         self._arr(x_enc, "x_enc", count, 2 * nw)
         self._arr(y_enc, "y_enc", count, 2 * nw)
         self._arr(r, "r", count, nw)
-        self._arr(rho_z, "rho_z", count, nw, optional=True)
+        self._arr(rho_z, "rho_z", count, 2 * nw if ready else nw, optional=True)
         z = self.empty(count, 2 * nw)
         alpha = torch.empty((count,), dtype=torch.int64, device=self.device)
         alpha_t, rsmall = torch.empty_like(alpha), torch.empty_like(alpha)
         rshift = self.empty(count, nw)
         self._sync_stream()
-        rc = self.lib.sc_initiator_step1(self.ctx, key.id, int(l), self._ptr(x_enc), self._ptr(y_enc), self._ptr(r), self._ptr(rho_z), self._ptr(z),
+        rc = self.lib.sc_initiator_step1(self.ctx, key.id, int(l), self._ptr(x_enc), self._ptr(y_enc), self._ptr(r), self._ptr(rho_z), int(ready), self._ptr(z),
                                          self._ptr(alpha), self._ptr(alpha_t), self._ptr(rsmall), self._ptr(rshift), count)
         self._check(rc)
         return z, alpha, alpha_t, rsmall, rshift
 
-    def keyholder_step2_4b(self, pkey: PaillierKey, dkey: DgkKey, l: int, z_enc: torch.Tensor, r_rand: torch.Tensor | None = None):
+    def keyholder_step2_4b(self, pkey: PaillierKey, dkey: DgkKey, l: int, z_enc: torch.Tensor, r_rand: torch.Tensor | None = None,
+                           ready: bool = False):
         """(z, beta, d, zeta_1, zeta_2, [d],[beta_i] as [l+1][B][nw]): KeyHolder.step_2 / 4a / 4b (+ their randomizations)."""
         count = self._items(z_enc)
         nw, nd = pkey.mod_n.nwords, dkey.mod_n.nwords
         self._arr(z_enc, "z_enc", count, 2 * nw)
-        self._arr(r_rand, "r_rand", (l + 1) * count, optional=True)
+        self._arr(r_rand, "r_rand", (l + 1) * count, nd if ready else None, optional=True)
         z, zeta1, zeta2 = self.empty(count, nw), self.empty(count, nw), self.empty(count, nw)
         beta = torch.empty((count,), dtype=torch.int64, device=self.device)
         dbit = torch.empty_like(beta)
         out = torch.empty((l + 1, count, nd), dtype=torch.int32, device=self.device)
         self._sync_stream()
         self._check(self.lib.sc_keyholder_step2_4b(self.ctx, pkey.id, dkey.id, int(l), self._ptr(z_enc), self._ptr(r_rand),
-                                                   0 if r_rand is None else r_rand.shape[-1], self._ptr(z), self._ptr(beta), self._ptr(dbit),
+                                                   0 if r_rand is None else r_rand.shape[-1], int(ready), self._ptr(z), self._ptr(beta), self._ptr(dbit),
                                                    self._ptr(zeta1), self._ptr(zeta2), self._ptr(out), count))
         return z, beta, dbit, zeta1, zeta2, out
 
     def initiator_step4(self, key: DgkKey, l: int, d_enc: torch.Tensor, beta_enc: torch.Tensor, alpha: torch.Tensor, alpha_tilde: torch.Tensor,
                         rsmall: torch.Tensor, delta_a: torch.Tensor, rhos: torch.Tensor | None = None, permutation: torch.Tensor | None = None,
-                        r_rand: torch.Tensor | None = None, want_unblinded: bool = False):
-        """(c, c after step 4h or None): Initiator.step_4c .. 4i for a batch; see sc_initiator_step4."""
+                        r_rand: torch.Tensor | None = None, want_unblinded: bool = False, ready: bool = False):
+        """(c, c after step 4h or None): Initiator.step_4c .. 4i for a batch; see sc_initiator_step4 (`ready`: r_rand holds h^r)."""
         count = self._items(d_enc)
         nw = key.mod_n.nwords
         self._arr(d_enc, "d_enc", count, nw)
         self._arr(beta_enc, "beta_enc", l * count, nw)
         self._flags(count, alpha=alpha, alpha_tilde=alpha_tilde, rsmall=rsmall, delta_a=delta_a)
         self._arr(rhos, "rhos", (l + 1) * count, optional=True)
-        self._arr(r_rand, "r_rand", (l + 1) * count, optional=True)
+        self._arr(r_rand, "r_rand", (l + 1) * count, nw if ready else None, optional=True)
         if permutation is not None:
             self._arr(permutation, "permutation", dtype=torch.int64)
             if tuple(permutation.shape) != (count, l + 1):
@@ -655,15 +657,15 @@ class Engine:
         self._sync_stream()
         rc = self.lib.sc_initiator_step4(self.ctx, key.id, int(l), self._ptr(d_enc), self._ptr(beta_enc), self._ptr(alpha), self._ptr(alpha_tilde),
                                          self._ptr(rsmall), self._ptr(delta_a), self._ptr(rhos), 0 if rhos is None else rhos.shape[-1],
-                                         self._ptr(permutation), self._ptr(r_rand), 0 if r_rand is None else r_rand.shape[-1], self._ptr(mid),
-                                         self._ptr(out), count)
+                                         self._ptr(permutation), self._ptr(r_rand), 0 if r_rand is None else r_rand.shape[-1], int(ready),
+                                         self._ptr(mid), self._ptr(out), count)
         if rc == -3:
             raise NotInvertibleError(self.lib.sc_last_error(self.ctx).decode())
         self._check(rc)
         return out, mid
 
     def initiator_step4i(self, key: DgkKey, l: int, c_in: torch.Tensor, rhos: torch.Tensor, permutation: torch.Tensor | None = None,
-                         r_rand: torch.Tensor | None = None) -> torch.Tensor:
+                         r_rand: torch.Tensor | None = None, ready: bool = False) -> torch.Tensor:
         """Blinding c_i^rho_i [* h^r_i] and the per-comparison shuffle of a vector [l+1][B][nw] that is already there."""
         nw = key.mod_n.nwords
         if c_in.dim() != 3 or c_in.shape[0] != l + 1:
@@ -671,7 +673,7 @@ class Engine:
         count = c_in.shape[1]
         self._arr(c_in, "c", (l + 1) * count, nw)
         self._arr(rhos, "rhos", (l + 1) * count)
-        self._arr(r_rand, "r_rand", (l + 1) * count, optional=True)
+        self._arr(r_rand, "r_rand", (l + 1) * count, nw if ready else None, optional=True)
         if permutation is not None:
             self._arr(permutation, "permutation", dtype=torch.int64)
             if tuple(permutation.shape) != (count, l + 1):
@@ -679,23 +681,23 @@ class Engine:
         out = torch.empty_like(c_in)
         self._sync_stream()
         self._check(self.lib.sc_initiator_step4i(self.ctx, key.id, int(l), self._ptr(c_in), self._ptr(rhos), rhos.shape[-1], self._ptr(permutation),
-                                                 self._ptr(r_rand), 0 if r_rand is None else r_rand.shape[-1], self._ptr(out), count))
+                                                 self._ptr(r_rand), 0 if r_rand is None else r_rand.shape[-1], int(ready), self._ptr(out), count))
         return out
 
     def keyholder_step4j_5(self, pkey: PaillierKey, dkey: DgkKey, l: int, c_enc: torch.Tensor, zeta1: torch.Tensor, zeta2: torch.Tensor,
-                           rho3: torch.Tensor | None = None):
+                           rho3: torch.Tensor | None = None, ready: bool = False):
         """(delta_B int64 [B], [[zeta_1]] | [[zeta_2]] | [[delta_B]] as [3B][2nw]): KeyHolder.step_4j / step_5 (+ randomizations)."""
         nw, nd = pkey.mod_n.nwords, dkey.mod_n.nwords
         count = self._items(zeta1)
         self._arr(c_enc, "c_enc", (l + 1) * count, nd)
         self._arr(zeta1, "zeta_1", count, nw)
         self._arr(zeta2, "zeta_2", count, nw)
-        self._arr(rho3, "rho3", 3 * count, nw, optional=True)
+        self._arr(rho3, "rho3", 3 * count, 2 * nw if ready else nw, optional=True)
         delta_b = torch.empty((count,), dtype=torch.int64, device=self.device)
         out = self.empty(3 * count, 2 * nw)
         self._sync_stream()
         self._check(self.lib.sc_keyholder_step4j_5(self.ctx, pkey.id, dkey.id, int(l), self._ptr(c_enc), self._ptr(zeta1), self._ptr(zeta2),
-                                                   self._ptr(rho3), self._ptr(delta_b), self._ptr(out), count))
+                                                   self._ptr(rho3), int(ready), self._ptr(delta_b), self._ptr(out), count))
         return delta_b, out
 
     def initiator_step67(self, key: PaillierKey, delta_a: torch.Tensor, delta_b_enc: torch.Tensor, zeta1_enc: torch.Tensor, zeta2_enc: torch.Tensor,

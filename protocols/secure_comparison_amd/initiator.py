@@ -256,24 +256,27 @@ class Initiator:
     # ------------------------------------------------------------------ batched steps (device arrays): one library call each
     @staticmethod
     def step_1_batch(x_enc: torch.Tensor, y_enc: torch.Tensor, l: int, scheme_paillier: Paillier, r: torch.Tensor,
-                     rho_z: torch.Tensor | None = None) -> tuple[torch.Tensor, AlicePlain]:
+                     rho_z: torch.Tensor | None = None, randomizers_ready: bool = False) -> tuple[torch.Tensor, AlicePlain]:
         """B times step 1 + step 3 + the plaintext side of 4c/4e/7 (sc_initiator_step1).  x_enc, y_enc: [B][2nw]; r: [B][nw]
-        (injected); rho_z: [B][nw] = the `.randomize()` of [[z]] (SC/initiator.py:109) fused in."""
+        (injected); rho_z: [B][nw] = the `.randomize()` of [[z]] (SC/initiator.py:109) fused in -- or, with
+        `randomizers_ready`, the finished randomizers rho_z^N mod N^2 ([B][2nw]) computed ahead of time."""
         n = scheme_paillier.public_key.n
         assert (1 << (l + 2)) < n // 2
-        z, alpha, alpha_tilde, r_small, r_shift = scheme_paillier.engine.initiator_step1(scheme_paillier.key, l, x_enc, y_enc, r, rho_z)
+        z, alpha, alpha_tilde, r_small, r_shift = scheme_paillier.engine.initiator_step1(scheme_paillier.key, l, x_enc, y_enc, r, rho_z,
+                                                                                         randomizers_ready)
         return z, AlicePlain(r, alpha, alpha_tilde, r_small, r_shift)
 
     @staticmethod
     def step_4_batch(d_enc: torch.Tensor, beta_is_enc: torch.Tensor, plain: AlicePlain, delta_a: torch.Tensor, scheme_dgk: DGK,
                      rhos: torch.Tensor, permutation: torch.Tensor | None = None, randomizer_exponents: torch.Tensor | None = None,
-                     want_unblinded: bool = False) -> tuple[torch.Tensor, torch.Tensor | None]:
+                     want_unblinded: bool = False, randomizers_ready: bool = False) -> tuple[torch.Tensor, torch.Tensor | None]:
         """Steps 4c .. 4i for B comparisons in ONE library call (sc_initiator_step4): the inversion pass over [d], [beta_i], the
         fused steps 4c-4h, the blinding c_i^rho_i, the re-randomization * h^r_i (`randomizer_exponents`) and the shuffle.
+        With `randomizers_ready`, `randomizer_exponents` holds the finished h^r_i ([l+1][B][nw]) instead of the exponents.
         Returns ([c_i] as sent: [l+1][B][nw], and the unblinded vector of step 4h when `want_unblinded`)."""
         l = beta_is_enc.shape[0]
         return scheme_dgk.engine.initiator_step4(scheme_dgk.key, l, d_enc, beta_is_enc, plain.alpha, plain.alpha_tilde, plain.r_small, delta_a,
-                                                 rhos, permutation, randomizer_exponents, want_unblinded)
+                                                 rhos, permutation, randomizer_exponents, want_unblinded, randomizers_ready)
 
     @staticmethod
     def step_4c_to_4h_batch(d_enc: torch.Tensor, beta_is_enc: torch.Tensor, plain: AlicePlain, delta_a: torch.Tensor,

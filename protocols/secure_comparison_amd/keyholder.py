@@ -189,24 +189,26 @@ class KeyHolder:
 
     @staticmethod
     def step_2_4b_batch(z_enc: torch.Tensor, l: int, scheme_paillier: Paillier, scheme_dgk: DGK,
-                        randomizer_exponents: torch.Tensor | None = None) -> tuple[BobPlain, torch.Tensor, torch.Tensor]:
+                        randomizer_exponents: torch.Tensor | None = None, randomizers_ready: bool = False) -> tuple[BobPlain, torch.Tensor, torch.Tensor]:
         """Steps 2, 4a, 4b (and, with `randomizer_exponents` [l+1][B][ew], the l + 1 `.randomize()` of SC/keyholder.py:106-108) in ONE
         library call (sc_keyholder_step2_4b).  Returns (plain, [d] as [B][nw], [beta_i] as [l][B][nw]) -- the latter two are the
         planes of one array, so the initiator's inversion pass takes them without a copy."""
         assert scheme_dgk.public_key.u > (1 << (l + 2))
         count = z_enc.shape[0]
         rr = None if randomizer_exponents is None else randomizer_exponents.reshape((l + 1) * count, -1)
-        z, beta, d, zeta_1, zeta_2, enc = scheme_paillier.engine.keyholder_step2_4b(scheme_paillier.key, scheme_dgk.key, l, z_enc, rr)
+        z, beta, d, zeta_1, zeta_2, enc = scheme_paillier.engine.keyholder_step2_4b(scheme_paillier.key, scheme_dgk.key, l, z_enc, rr,
+                                                                                    randomizers_ready)
         return BobPlain(z, beta, d, zeta_1, zeta_2), enc[0], enc[1:]
 
     @staticmethod
     def step_4j_5_batch(c_is_enc: torch.Tensor, plain: BobPlain, scheme_paillier: Paillier, scheme_dgk: DGK,
-                        rho3: torch.Tensor | None = None) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+                        rho3: torch.Tensor | None = None, randomizers_ready: bool = False) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
         """Steps 4j and 5 (and, with rho3 [3B][nw] = the bases for [[zeta_1]], [[zeta_2]], [[delta_B]] in that order, the three
         `.randomize()` of SC/keyholder.py:126-128) in ONE library call (sc_keyholder_step4j_5).
         Returns (delta_B [B] u64, [[zeta_1]], [[zeta_2]], [[delta_B]])."""
         l, count = c_is_enc.shape[0] - 1, c_is_enc.shape[1]
-        delta_b, enc = scheme_paillier.engine.keyholder_step4j_5(scheme_paillier.key, scheme_dgk.key, l, c_is_enc, plain.zeta_1, plain.zeta_2, rho3)
+        delta_b, enc = scheme_paillier.engine.keyholder_step4j_5(scheme_paillier.key, scheme_dgk.key, l, c_is_enc, plain.zeta_1, plain.zeta_2, rho3,
+                                                                 randomizers_ready)
         return delta_b, enc[:count], enc[count:2 * count], enc[2 * count:]
 
     @staticmethod

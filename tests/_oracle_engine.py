@@ -136,15 +136,15 @@ class OracleEngine:
         planes, count, nw = c.shape
         return self.modexp_shared_isone_any(key.mod_p, c.reshape(planes * count, nw), key.sk.v_p, count)
 
-    def initiator_step1(self, key, l, x_enc, y_enc, r, rho_z=None):
+    def initiator_step1(self, key, l, x_enc, y_enc, r, rho_z=None, ready=False):
         n, n2 = key.mod_n.n, key.mod_n2.n
         m1, alpha, alpha_t, rsmall, rshift = self.plain_alice(r, n, l)
         z = self.modmul(key.mod_n2, self.modmul(key.mod_n2, y_enc, self.modinv(key.mod_n2, x_enc)), self.paillier_encrypt(key, m1))
         if rho_z is not None:
-            z = self.paillier_randomize(key, z, rho_z)
+            z = self.modmul(key.mod_n2, z, rho_z) if ready else self.paillier_randomize(key, z, rho_z)
         return z, alpha, alpha_t, rsmall, rshift
 
-    def keyholder_step2_4b(self, pkey, dkey, l, z_enc, r_rand=None):
+    def keyholder_step2_4b(self, pkey, dkey, l, z_enc, r_rand=None, ready=False):
         count = z_enc.shape[0]
         z = self.paillier_decrypt(pkey, z_enc)
         beta, dbit, zeta1, zeta2 = self.plain_bob(z, pkey.mod_n.n, l)
@@ -153,41 +153,51 @@ class OracleEngine:
         for i in range(l):
             bits += [((int(v) & M) >> i) & 1 for v in beta.tolist()]
         bt = torch.tensor(bits, dtype=torch.uint8)
-        if r_rand is not None:
+        if r_rand is not None and ready:
+            enc = self.modmul_const_sel(dkey.mod_n, r_rand, None, dkey.sk.g, bt)
+        elif r_rand is not None:
             enc = self.dgk_encrypt_bits_randomized(dkey, bt, r_rand)
         else:
             enc = self.upload([dkey.sk.g if b else 1 for b in bits], dkey.mod_n.nwords)
         return z, beta, dbit, zeta1, zeta2, enc.reshape(l + 1, count, -1)
 
-    def initiator_step4i(self, key, l, c_in, rhos, permutation=None, r_rand=None):
+    def initiator_step4i(self, key, l, c_in, rhos, permutation=None, r_rand=None, ready=False):
         lp1, count, nw = c_in.shape
         dest = None
         if permutation is not None:
             planes = torch.arange(lp1, dtype=torch.int64).expand(count, lp1)
             inverse = torch.zeros_like(permutation).scatter_(1, permutation.clamp(0, lp1 - 1), planes)
             dest = (inverse.t() * count + torch.arange(count, dtype=torch.int64)).reshape(-1)
+        if ready and r_rand is not None:        # h^r computed ahead: blind, multiply, then place
+            flat = self.modexp_var(key.mod_n, c_in.reshape(lp1 * count, nw), rhos.reshape(lp1 * count, -1), 0)
+            flat = self.modmul(key.mod_n, flat, r_rand.reshape(lp1 * count, nw))
+            if dest is not None:
+                placed = torch.zeros_like(flat)
+                placed[dest] = flat
+                flat = placed
+            return flat.reshape(lp1, count, nw)
         fb = FixedBase(0, key.mod_n, key.sk.h) if r_rand is not None else None
         flat = self.modexp_var(key.mod_n, c_in.reshape(lp1 * count, nw), rhos.reshape(lp1 * count, -1), 0, fb,
                                None if r_rand is None else r_rand.reshape(lp1 * count, -1), dest=dest)
         return flat.reshape(lp1, count, nw)
 
     def initiator_step4(self, key, l, d_enc, beta_enc, alpha, alpha_tilde, rsmall, delta_a, rhos=None, permutation=None, r_rand=None,
-                        want_unblinded=False):
+                        want_unblinded=False, ready=False):
         count, nw = d_enc.shape
         inv = self.modinv(key.mod_n, torch.cat([d_enc.reshape(1, count, nw), beta_enc]).reshape((l + 1) * count, nw))
         c_h = self.dgk_step4(key.mod_n, key.sk.g, o.mod_inv(key.sk.g, key.mod_n.n), l, beta_enc, inv[count:].reshape(l, count, nw), d_enc,
                              inv[:count], alpha, alpha_tilde, rsmall, delta_a)
         if rhos is None:
             return c_h, None
-        return self.initiator_step4i(key, l, c_h, rhos, permutation, r_rand), (c_h if want_unblinded else None)
+        return self.initiator_step4i(key, l, c_h, rhos, permutation, r_rand, ready), (c_h if want_unblinded else None)
 
-    def keyholder_step4j_5(self, pkey, dkey, l, c_enc, zeta1, zeta2, rho3=None):
+    def keyholder_step4j_5(self, pkey, dkey, l, c_enc, zeta1, zeta2, rho3=None, ready=False):
         count = zeta1.shape[0]
         delta_b = self.dgk_any_zero(dkey, c_enc.reshape(l + 1, count, -1))
         db = self.upload([int(v) for v in delta_b.tolist()], zeta1.shape[-1])
         enc = self.paillier_encrypt(pkey, torch.cat([zeta1, zeta2, db], dim=0))
         if rho3 is not None:
-            enc = self.paillier_randomize(pkey, enc, rho3)
+            enc = self.modmul(pkey.mod_n2, enc, rho3) if ready else self.paillier_randomize(pkey, enc, rho3)
         return delta_b, enc
 
     def initiator_step67(self, key, delta_a, delta_b_enc, zeta1_enc, zeta2_enc, rsmall, rshift):

@@ -242,13 +242,13 @@ def test_scheme_level_c_abi_with_ctypes_only(keys):
             d_r, d_rho_z = dev(ints_to_words([d.r for d in drs], nw)), dev(ints_to_words([d.rho_z for d in drs], nw))
             d_z, d_alpha, d_alpha_t, d_rsmall, d_rshift = empty(B, 2 * nw), empty(B, dtype=np.uint64), empty(B, dtype=np.uint64), \
                 empty(B, dtype=np.uint64), empty(B, nw)
-            assert lib.sc_initiator_step1(ctx, a_key, l, d_x, d_y, d_r, d_rho_z, d_z, d_alpha, d_alpha_t, d_rsmall, d_rshift, B) == 0, lib.sc_last_error(ctx)
+            assert lib.sc_initiator_step1(ctx, a_key, l, d_x, d_y, d_r, d_rho_z, 0, d_z, d_alpha, d_alpha_t, d_rsmall, d_rshift, B) == 0, lib.sc_last_error(ctx)
             assert words_to_ints(back(d_z, B, 2 * nw)) == [t["z_enc"] for t in traces]
             # Bob: steps 2, 4a, 4b (+ l + 1 randomizations)
             d_rb = dev(planes([[d.r_d] + d.r_beta for d in drs], er))
             d_zp, d_beta, d_dbit, d_z1, d_z2, d_db = empty(B, nw), empty(B, dtype=np.uint64), empty(B, dtype=np.uint64), empty(B, nw), \
                 empty(B, nw), empty(l + 1, B, nd)
-            assert lib.sc_keyholder_step2_4b(ctx, b_key, b_dgk, l, d_z, d_rb, er, d_zp, d_beta, d_dbit, d_z1, d_z2, d_db, B) == 0, lib.sc_last_error(ctx)
+            assert lib.sc_keyholder_step2_4b(ctx, b_key, b_dgk, l, d_z, d_rb, er, 0, d_zp, d_beta, d_dbit, d_z1, d_z2, d_db, B) == 0, lib.sc_last_error(ctx)
             assert words_to_ints(back(d_zp, B, nw)) == [t["z"] for t in traces]
             got_db = back(d_db, l + 1, B, nd)
             assert words_to_ints(got_db[0]) == [t["d_sent"] for t in traces]
@@ -263,14 +263,14 @@ def test_scheme_level_c_abi_with_ctypes_only(keys):
             d_da = dev(np.array([d.delta_a for d in drs], dtype=np.uint64))
             d_c = empty(l + 1, B, nd)
             beta_ptr = C.c_void_p(d_db.value + B * nd * 4)      # [beta_i] = planes 1.. of the same array: no copy inside
-            assert lib.sc_initiator_step4(ctx, a_dgk, l, d_db, beta_ptr, d_alpha, d_alpha_t, d_rsmall, d_da, d_rhos, ew, d_perm, d_ra, er, None,
+            assert lib.sc_initiator_step4(ctx, a_dgk, l, d_db, beta_ptr, d_alpha, d_alpha_t, d_rsmall, d_da, d_rhos, ew, d_perm, d_ra, er, 0, None,
                                           d_c, B) == 0, lib.sc_last_error(ctx)
             got_c = back(d_c, l + 1, B, nd)
             assert [words_to_ints(got_c[:, b]) for b in range(B)] == [t["c_enc"] for t in traces]
             # Bob: steps 4j, 5 (+ 3 randomizations)
             d_rho3 = dev(np.concatenate([ints_to_words([getattr(d, f) for d in drs], nw) for f in ("rho_zeta1", "rho_zeta2", "rho_delta_b")]))
             d_delta_b, d_out3 = empty(B, dtype=np.uint64), empty(3, B, 2 * nw)
-            assert lib.sc_keyholder_step4j_5(ctx, b_key, b_dgk, l, d_c, d_z1, d_z2, d_rho3, d_delta_b, d_out3, B) == 0, lib.sc_last_error(ctx)
+            assert lib.sc_keyholder_step4j_5(ctx, b_key, b_dgk, l, d_c, d_z1, d_z2, d_rho3, 0, d_delta_b, d_out3, B) == 0, lib.sc_last_error(ctx)
             assert back(d_delta_b, B, dtype=np.uint64).tolist() == [t["delta_b"] for t in traces]
             # Alice: steps 6, 7
             d_res = empty(B, 2 * nw)
@@ -298,3 +298,36 @@ def test_scheme_level_c_abi_with_ctypes_only(keys):
             for p in live:
                 lib.sc_free(ctx, p)
             lib.sc_ctx_destroy(ctx)
+
+
+@pytest.mark.parametrize("B, shuffle", [(300, True), (9000, False)])
+def test_randomizers_on_a_second_stream_give_the_same_residues(engine, keys, B, shuffle):
+    """secure_comparison_batch(side=...): the 4 + 2(l+1) randomizer exponentiations run on a second library context and stream and
+    are applied with one product each (SC_STEP_RANDOMIZERS_READY) -- every wire value and the result equal the fused path's."""
+    import bench
+    from protocols.secure_comparison_amd import DGK, Paillier
+    from protocols.secure_comparison_amd.batch import BatchTrace, PartySet, secure_comparison_batch
+    from protocols.secure_comparison_amd.engine import Engine
+
+    sk, dgk = oracle_paillier(keys, 2048), oracle_dgk(keys, "dgk_2048_l32")
+    l = 32
+    alice_p, alice_d, bob_p, bob_d = _schemes(engine, sk, dgk, 400)
+    e2 = Engine()
+    bob_p2 = Paillier(sk.n, sk.p, sk.q, engine=e2)
+    bob_d2 = DGK(dgk.n, dgk.g, dgk.h, dgk.u, dgk.t, dgk.p, dgk.q, dgk.v_p, dgk.v_q, engine=e2, randomizer_bits=400)
+    alice_d2 = bob_d2.public_copy()
+    bob_d2.share_tables_from(bob_d), alice_d2.share_tables_from(alice_d)
+    side = PartySet(bob_p2.public_copy(), alice_d2, bob_p2, bob_d2, torch.cuda.Stream())
+    x, y, x_enc, y_enc, draws = bench.synth_inputs(engine, l, alice_p, bob_p, bob_d, B, 400, seed=21, shuffle=shuffle)
+    t1, t2 = BatchTrace(), BatchTrace()
+    fused = secure_comparison_batch(x_enc, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws, True, t1)
+    split = secure_comparison_batch(x_enc, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws, True, t2, side=side)
+    torch.cuda.synchronize()
+    for name in ("z_enc", "z", "d_enc", "beta_enc", "c_step4h", "c_sent", "delta_b", "zeta_1_enc", "zeta_2_enc", "delta_b_enc"):
+        assert torch.equal(getattr(t1, name), getattr(t2, name)), name
+    assert torch.equal(fused, split)
+    dec = bob_p.decrypt_raw_batch(split)
+    assert bool(((dec[:, 0] == (x <= y).to(torch.int32)) & (dec[:, 1:] == 0).all(dim=1)).all().item())
+    idx = [0, 1, B // 2, B - 1]
+    assert engine.download(split[torch.tensor(idx, device=engine.device)]) == _oracle_rows(engine, idx, l, sk, dgk, x_enc, y_enc, draws)
+    e2.close()

@@ -190,6 +190,17 @@ def test_batch_driver_layout_and_shuffle(world, use_crt):
     got = secure_comparison_batch(eng.upload(x_enc, 2 * nw), eng.upload(y_enc, 2 * nw), L, bob_p.public_copy(), bob_d.public_copy(),
                                   bob_p, bob_d, draws, True, tr)
     assert eng.download(got) == expect
+    # the same batch with the randomizer exponentiations taken out of the steps and computed on a second context (`side`)
+    from protocols.secure_comparison_amd.batch import PartySet
+
+    eng2 = OracleEngine()
+    bob_p2 = Paillier(osk.n, osk.p, osk.q, engine=eng2, use_crt=use_crt)
+    bob_d2 = DGK(od.n, od.g, od.h, od.u, od.t, od.p, od.q, od.v_p, od.v_q, engine=eng2, randomizer_bits=50)
+    side = PartySet(bob_p2.public_copy(), bob_d2.public_copy(), bob_p2, bob_d2, None)
+    tr2 = BatchTrace()
+    got2 = secure_comparison_batch(eng.upload(x_enc, 2 * nw), eng.upload(y_enc, 2 * nw), L, bob_p.public_copy(), bob_d.public_copy(),
+                                   bob_p, bob_d, draws, True, tr2, side=side)
+    assert eng.download(got2) == expect and torch.equal(tr2.c_sent, tr.c_sent) and torch.equal(tr2.beta_enc, tr.beta_enc)
     assert [eng.download(tr.c_sent[:, b])for b in range(B)] == [t["c_enc"] for t in traces]
     assert tr.delta_b.tolist() == [t["delta_b"] for t in traces]
     assert [osk.dec_raw(v) for v in eng.download(got)] == [int(x <= y) for x, y in zip(xs, ys)]
