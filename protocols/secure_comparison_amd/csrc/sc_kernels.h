@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(64, (G == 1 && L == 37) ? 2 : (L == 27 ? SC_L2
 // "pair arithmetic").  Same launch geometry and argument block as k_vm; compiled for the L = 18 configurations.
 // ---------------------------------------------------------------------------------------------
 template <int G, int L, int WB>
-__global__ void __launch_bounds__(64, (G == 16 ? 1 : SC_PVM_WAVES)) k_pvm(const VmArgs args) {
+__global__ void __launch_bounds__(64, ((G == 16 && L > 9) ? 1 : SC_PVM_WAVES)) k_pvm(const VmArgs args) {
   using GT = Grp<G, L, WB>;
   constexpr int S = GT::S, NG = GT::NG, SP = GT::SP, WP = GT::WP;
   __shared__ uint32_t s_a[NG * SP];            // first LDS-side operand  (x0, or y0)

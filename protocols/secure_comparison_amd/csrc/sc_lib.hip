@@ -125,7 +125,15 @@ const Config kOneLane = {1, 37, 28, false};
 // (2, 18) ones but its pair products -- three passes over a single LDS staging area, the second area would cost the eighth wave
 // of the CU -- 2.6x a squaring instead of 1.4x, a net loss of 12 % on x^p mod p^2; the one-lane form is used where it wins:
 // the single-modulus exponentiations)
-inline bool pair_capable(int G, int L, int W) { return W == 29 && (L == 18 || (L == 14 && (G == 4 || G == 8))); }
+// (8,5) / (16,5): the SMALL-BATCH pair configurations of 1024 / 2048-bit moduli (kLatencyPair below)
+inline bool pair_capable(int G, int L, int W) { return W == 29 && (L == 18 || (L == 14 && (G == 4 || G == 8)) || (L == 5 && (G == 8 || G == 16))); }
+// Small batches of pair exponentiations (Alice's rho^N mod N^2, the key holder's c^(p-1) mod p^2 at B = 4096) are one dependent
+// chain of ~2400 pair squarings per item, and a wave's time per squaring is its own instruction count: S limb steps of
+// (L + L/2) multiply-adds + ~7 bookkeeping instructions each, whatever the number of lanes.  When even the (2G, 9) form
+// leaves half of the SIMDs without a wave, 4x the lanes with 5 limbs each -- (16,5) for 2048-bit, (8,5) for 1024-bit moduli,
+// S = 80 / 40 limbs -- shorten every limb step from ~22 to ~15 instructions at a multiply-add density (45 %) that would be
+// wasteful on a full chip but costs nothing on an empty one.  A twin context of the same modulus, like the other twins.
+const Config kLatencyPair16 = {16, 5, 29, false}, kLatencyPair8 = {8, 5, 29, false};
 
 struct Mod {
   int G = 0, L = 0, W = 29, S = 0, nwords = 0, nbits = 0;
@@ -179,6 +187,7 @@ struct sc_ctx {
   int comm_rank = 0, comm_nranks = 0;
   std::map<int, int> onelane_twins;                         // mod -> context of the same modulus in the one-lane configuration
   std::map<int, int> pair_twins;                            // mod -> context of the same modulus in a pair-capable configuration
+  std::map<int, int> latency_pair_twins;                    // mod -> context of the same modulus in the (16,5) / (8,5) small-batch pair configuration
   std::map<int, uint32_t*> pair_consts;                     // mod -> 4 limb arrays: pair(R^2), pair(B R) for the pair arithmetic
   RngKey rng_key;                                           // ChaCha20 key of the context's generator (sc_rng_seed)
   void* scheme_keys = nullptr;                              // Paillier / DGK key objects of the scheme-level entry points (sc_schemes.h)
@@ -464,6 +473,10 @@ int run_pvm(sc_ctx* ctx, int mod, const Prog& p, const VmExt* exts, int next, ui
   if (m.L == 14) switch (m.G) {
     case 4: return launch_pvm_cfg<4, 14>(ctx, a);
     case 8: return launch_pvm_cfg<8, 14>(ctx, a);
+  }
+  if (m.L == 5) switch (m.G) {
+    case 8: return launch_pvm_cfg<8, 5>(ctx, a);
+    case 16: return launch_pvm_cfg<16, 5>(ctx, a);
   }
   return fail(ctx, SC_ERR_UNSUPPORTED, "no pair kernel for G=%d", m.G);
 }
@@ -1359,6 +1372,28 @@ static int pair_twin(sc_ctx* ctx, int mod) {
   return twin;
 }
 
+// The small-batch pair twin of `mod` ((16,5) for a (4,18) modulus, (8,5) for a (2,18) one) when this batch should run on it, else
+// -1.  Automatic policy: the (2G, 9) launch would still leave at least half of the SIMDs without a wave.
+static int latency_pair_twin(sc_ctx* ctx, int mod, uint64_t count) {
+  if (ctx->latency_mode == 0) return -1;
+  const Config* cfg = nullptr;
+  {
+    const Mod& m = ctx->mods[mod];
+    if (m.W != 29 || m.L != 18 || (m.G != 2 && m.G != 4)) return -1;
+    cfg = (m.G == 4) ? &kLatencyPair16 : &kLatencyPair8;
+    const uint64_t per_wave = 64 / (2 * m.G), waves = (count + per_wave - 1) / per_wave;
+    if (ctx->latency_mode == 1 && waves > (uint64_t)ctx->num_cu * 2 / (uint64_t)ctx->chip_share) return -1;
+    if (m.nbits + 8 > cfg->W * cfg->G * cfg->L || 32 * m.nwords > cfg->W * cfg->G * cfg->L) return -1;
+  }
+  auto it = ctx->latency_pair_twins.find(mod);
+  if (it != ctx->latency_pair_twins.end()) return it->second;
+  const Big n = ctx->mods[mod].n;
+  int twin = -1;
+  if (create_mod(ctx, n.data(), (int)n.size(), false, &twin, cfg) != SC_OK) twin = -1;
+  ctx->latency_pair_twins[mod] = twin;
+  return twin;
+}
+
 // The one-lane twin of `mod` when this batch should run on it, else `mod` itself.  Automatic policy: the modulus fits the
 // one-lane configuration and the batch is at least one and a half rounds of the chip's resident one-lane waves (2 per SIMD, 64
 // numbers each: 196608 numbers on 256 CUs).  Measured on the MI355X (1024-bit modulus, 1024-bit exponent): 196608 numbers 19.8 ->
@@ -1406,7 +1441,10 @@ int sc_modexp_shared_sq(sc_ctx* ctx, int mod_m, int mod_m2, int exp, const uint3
   if (ctx && count == 0) return SC_OK;
   if (!valid_mod(ctx, mod_m) || !valid_mod(ctx, mod_m2) || exp < 0 || exp >= (int)ctx->exps.size() || !x || !out || x_words <= 0)
     return fail(ctx, SC_ERR_ARG, "sc_modexp_shared_sq: bad argument");
-  mod_m = pair_twin(ctx, mod_m);
+  {
+    const int lat = latency_pair_twin(ctx, mod_m, count);
+    mod_m = lat >= 0 ? lat : pair_twin(ctx, mod_m);
+  }
   if (mod_m < 0) return fail(ctx, SC_ERR_UNSUPPORTED, "sc_modexp_shared_sq: no pair configuration fits this modulus");
   const Mod& m = ctx->mods[mod_m];
   const Mod& m2 = ctx->mods[mod_m2];
