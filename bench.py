@@ -244,7 +244,7 @@ def parse_args(argv=None):
     ap.add_argument("--streams", type=int, default=0, help="concurrent shards per GPU (one library context, HIP stream and host thread each); 1 = a single stream; "
                     "0 = automatic: 2 from 65536 comparisons per GPU")
     ap.add_argument("--side-stream", type=int, default=-1, help="run the randomizer exponentiations of a step on a second library context and stream per shard, "
-                    "concurrently with the protocol's critical path (batch._AheadOfTime): 1 on, 0 off, -1 automatic (on below 65536 comparisons per GPU)")
+                    "concurrently with the protocol's critical path (batch._AheadOfTime): 1 on, 0 off, -1 automatic (on up to 8192 comparisons per GPU: measured +15 % at 4096, -2 % at 16384)")
     ap.add_argument("--latency-mode", type=int, default=1, help="small-batch kernel policy (sc_ctx_set_latency_mode): 0 never, 1 automatic, 2 always")
     ap.add_argument("--onelane-mode", type=int, default=1, help="large-batch kernel policy for the 1024-bit primes (sc_ctx_set_onelane_mode): 0 never, 1 automatic, 2 always")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -304,7 +304,7 @@ def main() -> None:
     eng = default_engine()
     ns = max(1, min(args.streams, B)) if args.streams > 0 else (2 if B >= 65536 else 1)
     ns = launcher.host_threads_per_rank(world, ns)      # shard threads of all ranks together stay within the node's cores
-    use_side = bool(args.side_stream) if args.side_stream >= 0 else (B < 65536)
+    use_side = bool(args.side_stream) if args.side_stream >= 0 else (B <= 8192)
     engines = [eng] + [Engine() for _ in range(1, ns)]
     side_engines = [Engine() for _ in range(ns)] if use_side else []
     for e_ in engines + side_engines:

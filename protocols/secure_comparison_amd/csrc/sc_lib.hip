@@ -190,6 +190,13 @@ struct sc_ctx {
   std::map<int, int> latency_pair_twins;                    // mod -> context of the same modulus in the (16,5) / (8,5) small-batch pair configuration
   std::map<int, uint32_t*> pair_consts;                     // mod -> 4 limb arrays: pair(R^2), pair(B R) for the pair arithmetic
   RngKey rng_key;                                           // ChaCha20 key of the context's generator (sc_rng_seed)
+  // fork / join inside one library call (AuxFork): independent halves of a small batch -- the p- and q-side of the key holder's CRT
+  // -- run on a second stream of the context with its own scratch arena and temporaries
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t aux_fork = nullptr, aux_join = nullptr;
+  uint32_t* scratch_aux = nullptr;
+  size_t scratch_aux_bytes = 0;
+  bool in_aux = false;
   void* scheme_keys = nullptr;                              // Paillier / DGK key objects of the scheme-level entry points (sc_schemes.h)
   bool rng_seeded = false;
   uint64_t rng_call = 0;                                    // generator calls since seeding: part of every keystream's nonce
@@ -223,20 +230,25 @@ int upload(sc_ctx* ctx, const void* h, size_t bytes, void** out) {
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return SC_OK;
 }
-int ensure_scratch(sc_ctx* ctx, size_t bytes) {
-  if (bytes <= ctx->scratch_bytes) return SC_OK;
-  if (ctx->scratch) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->scratch)); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
-  size_t want = bytes + bytes / 4;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  HIPCHK(ctx, hipMalloc((void**)&ctx->scratch, want));
-  ctx->scratch_bytes = want;
+// the scratch arena of the stream the context currently launches on (its own, or the forked one's: AuxFork)
+int ensure_scratch(sc_ctx* ctx, size_t bytes, uint32_t** out) {
+  uint32_t*& arena = ctx->in_aux ? ctx->scratch_aux : ctx->scratch;
+  size_t& have = ctx->in_aux ? ctx->scratch_aux_bytes : ctx->scratch_bytes;
+  if (bytes > have) {
+    if (arena) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(arena)); arena = nullptr; have = 0; }
+    size_t want = bytes + bytes / 4;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMalloc((void**)&arena, want));
+    have = want;
+  }
+  *out = arena;
   return SC_OK;
 }
 
 // Temporary device buffer `slot`, at least `bytes` large.  Buffers are reused by later calls: every kernel of a context
 // runs on one stream, so a later call cannot overtake an earlier one that still reads the buffer.
 int tmp_buf(sc_ctx* ctx, int slot, size_t bytes, void** out) {
-  auto& e = ctx->tmp[slot];
+  auto& e = ctx->tmp[slot + (ctx->in_aux ? 1000 : 0)];       // the forked stream's calls never share a temporary with the main one's
   if (e.second < bytes) {
     if (e.first) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(e.first)); e.first = nullptr; e.second = 0; }
     size_t want = bytes + bytes / 8 + 256;
@@ -247,6 +259,51 @@ int tmp_buf(sc_ctx* ctx, int slot, size_t bytes, void** out) {
   *out = e.first;
   return SC_OK;
 }
+// Fork / join inside one library call.  begin(): everything queued so far on the context's stream happens before the forked work;
+// until end() the context launches on its second stream (own scratch arena, own temporaries); end(): the context's stream waits
+// for the forked work.  Used for the q-side of the key holder's CRT when a launch of the batch leaves most of the chip idle.
+struct AuxFork {
+  sc_ctx* ctx = nullptr;
+  hipStream_t main = nullptr;
+  bool active = false;
+  int begin(sc_ctx* c) {
+    ctx = c;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->aux_stream) {
+      HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+      HIPCHK(c, hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming));
+      HIPCHK(c, hipEventCreateWithFlags(&c->aux_join, hipEventDisableTiming));
+    }
+    HIPCHK(c, hipEventRecord(c->aux_fork, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->aux_fork, 0));
+    main = c->stream;
+    c->stream = c->aux_stream;
+    c->in_aux = true;
+    active = true;
+    return SC_OK;
+  }
+  int end() {
+    if (!active) return SC_OK;
+    active = false;
+    sc_ctx* c = ctx;
+    const hipError_t e1 = hipEventRecord(c->aux_join, c->aux_stream);
+    c->stream = main;
+    c->in_aux = false;
+    if (e1 != hipSuccess) return fail(c, SC_ERR_HIP, "hipEventRecord: %s", hipGetErrorString(e1));
+    HIPCHK(c, hipStreamWaitEvent(main, c->aux_join, 0));
+    return SC_OK;
+  }
+  ~AuxFork() { (void)end(); }      // error paths: never leave the context on its second stream
+};
+// Is a launch of `count` items of modulus `mod` small enough that a second, independent one fits beside it?  (A wave per SIMD
+// for both: half of the chip's 4 x CUs SIMDs each.)  Off with latency mode 0.
+inline bool small_enough_to_fork(const sc_ctx* ctx, const Mod& m, uint64_t count) {
+  if (ctx->latency_mode == 0 || ctx->in_aux) return false;
+  if (ctx->latency_mode == 2) return true;
+  const uint64_t per_wave = std::max(1, 64 / (2 * m.G));     // in the small-batch configuration this batch would take
+  return (count + per_wave - 1) / per_wave <= (uint64_t)ctx->num_cu * 4 / (uint64_t)ctx->chip_share;
+}
+
 enum TmpSlot { TMP_PARK = 1, TMP_XGCD_STATUS = 2, TMP_CRT = 3, TMP_PAIR = 4, TMP_INV_MEMBERS = 5, TMP_INV_BASE = 16 /* + 2*depth, + 2*depth+1 */ };
 
 // device copy of n | (n-1)/2 as canonical words (plain-word kernels)
@@ -367,10 +424,9 @@ int launch_vm_cfg(sc_ctx* ctx, const VmArgs& a, int cfg_index) {
   uint64_t maxb = (uint64_t)ctx->num_cu * occ;
   uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min(need, maxb));
   size_t scratch_bytes = (size_t)grid * NG * a.nscratch * (G * L) * 4;
-  int rc = ensure_scratch(ctx, scratch_bytes);
-  if (rc) return rc;
   VmArgs args = a;
-  args.scratch = ctx->scratch;
+  int rc = ensure_scratch(ctx, scratch_bytes, &args.scratch);
+  if (rc) return rc;
   hipLaunchKernelGGL((k_vm<G, L, WB>), dim3(grid), dim3(64), 0, ctx->stream, args);
   HIPCHK(ctx, hipGetLastError());
   return SC_OK;
@@ -438,10 +494,9 @@ int launch_pvm_cfg(sc_ctx* ctx, const VmArgs& a) {
   }
   uint64_t need = (a.count + NG - 1) / NG;
   uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(need, (uint64_t)ctx->num_cu * occ));
-  int rc = ensure_scratch(ctx, (size_t)grid * NG * a.nscratch * (G * L) * 4);
-  if (rc) return rc;
   VmArgs args = a;
-  args.scratch = ctx->scratch;
+  int rc = ensure_scratch(ctx, (size_t)grid * NG * a.nscratch * (G * L) * 4, &args.scratch);
+  if (rc) return rc;
   hipLaunchKernelGGL((k_pvm<G, L, WB>), dim3(grid), dim3(64), 0, ctx->stream, args);
   HIPCHK(ctx, hipGetLastError());
   return SC_OK;
@@ -569,6 +624,10 @@ void sc_ctx_destroy(sc_ctx* ctx) {
   (void)hipDeviceSynchronize();
   for (void* p : ctx->owned) (void)hipFree(p);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->scratch_aux) (void)hipFree(ctx->scratch_aux);
+  if (ctx->aux_fork) (void)hipEventDestroy(ctx->aux_fork);
+  if (ctx->aux_join) (void)hipEventDestroy(ctx->aux_join);
+  if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
   for (auto& kv : ctx->tmp) if (kv.second.first) (void)hipFree(kv.second.first);
   if (ctx->switch_event) (void)hipEventDestroy(ctx->switch_event);
   if (ctx->comm) (void)sc_comm_destroy(ctx);

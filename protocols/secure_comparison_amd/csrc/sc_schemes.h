@@ -149,9 +149,15 @@ int paillier_crt_pow_n(sc_ctx* ctx, const PaillierKey& k, const uint32_t* rho, u
   int rc = tmp_words(ctx, TMP_S_A, count * k.hw, &y); if (rc) return rc;
   rc = tmp_words(ctx, TMP_S_B, count * 2 * k.hw, &part_p); if (rc) return rc;
   rc = tmp_words(ctx, TMP_S_C, count * 2 * k.hw, &part_q); if (rc) return rc;
+  AuxFork fork;
+  const bool forked = small_enough_to_fork(ctx, ctx->mods[k.hp.m1], count);
   for (int side = 0; side < 2; side++) {
     const PaillierHalf& h = side ? k.hq : k.hp;
     uint32_t* part = side ? part_q : part_p;
+    if (side == 1 && forked) {       // the q-side beside the p-side: a small batch leaves room for both
+      rc = fork.begin(ctx); if (rc) return rc;
+      rc = tmp_words(ctx, TMP_S_A, count * k.hw, &y); if (rc) return rc;
+    }
     rc = sc_modexp_shared(ctx, h.m1, h.exp_small, rho, k.nw, nullptr, y, count); if (rc) return rc;       // wide operand reduced mod p
     if (k.pairs && sc_mod_supports_sq(ctx, h.m1) == 1) {
       rc = sc_modexp_shared_sq(ctx, h.m1, h.m2, h.exp_p, y, k.hw, nullptr, part, count);
@@ -160,6 +166,7 @@ int paillier_crt_pow_n(sc_ctx* ctx, const PaillierKey& k, const uint32_t* rho, u
     }
     if (rc) return rc;
   }
+  rc = fork.end(); if (rc) return rc;
   return sc_crt_combine(ctx, k.hp.m2, k.mod_n2, k.r_k, k.r_negk, k.r_mq, part_p, 2 * k.hw, part_q, 2 * k.hw, out, count);
 }
 
@@ -285,13 +292,20 @@ int sc_paillier_decrypt(sc_ctx* ctx, int key, const uint32_t* c, uint32_t* out, 
   rc = tmp_words(ctx, TMP_S_A, count * 2 * k.hw, &x); if (rc) return rc;
   rc = tmp_words(ctx, TMP_S_B, count * k.hw, &m_p); if (rc) return rc;
   rc = tmp_words(ctx, TMP_S_C, count * k.hw, &m_q); if (rc) return rc;
+  AuxFork fork;
+  const bool forked = small_enough_to_fork(ctx, ctx->mods[k.hp.m1], count);
   for (int side = 0; side < 2; side++) {
     const PaillierHalf& h = side ? k.hq : k.hp;
+    if (side == 1 && forked) {       // c^(q-1) mod q^2 beside c^(p-1) mod p^2
+      rc = fork.begin(ctx); if (rc) return rc;
+      rc = tmp_words(ctx, TMP_S_A, count * 2 * k.hw, &x); if (rc) return rc;
+    }
     if (k.pairs && sc_mod_supports_sq(ctx, h.m1) == 1) rc = sc_modexp_shared_sq(ctx, h.m1, h.m2, h.exp_pm1, c, 2 * k.nw, nullptr, x, count);
     else rc = sc_modexp_shared(ctx, h.m2, h.exp_pm1, c, 2 * k.nw, nullptr, x, count);
     if (rc) return rc;
     rc = sc_paillier_l_mul(ctx, h.m1, h.cst_h, x, 2 * k.hw, side ? m_q : m_p, count); if (rc) return rc;
   }
+  rc = fork.end(); if (rc) return rc;
   return sc_crt_combine(ctx, k.hp.m1, k.mod_n, k.d_k, k.d_negk, k.d_mq, m_p, k.hw, m_q, k.hw, out, count);
 }
 
