@@ -245,6 +245,7 @@ def parse_args(argv=None):
                     "0 = automatic: 2 from 65536 comparisons per GPU")
     ap.add_argument("--side-stream", type=int, default=-1, help="run the randomizer exponentiations of a step on a second library context and stream per shard, "
                     "concurrently with the protocol's critical path (batch._AheadOfTime): 1 on, 0 off, -1 automatic (on up to 8192 comparisons per GPU: measured +15 % at 4096, -2 % at 16384)")
+    ap.add_argument("--side-fork", type=int, default=0, help="fork mode (sc_ctx_set_fork_mode) of the second contexts")
     ap.add_argument("--latency-mode", type=int, default=1, help="small-batch kernel policy (sc_ctx_set_latency_mode): 0 never, 1 automatic, 2 always")
     ap.add_argument("--onelane-mode", type=int, default=1, help="large-batch kernel policy for the 1024-bit primes (sc_ctx_set_onelane_mode): 0 never, 1 automatic, 2 always")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -310,6 +311,8 @@ def main() -> None:
     for e_ in engines + side_engines:
         e_.set_latency_mode(args.latency_mode)
         e_.set_onelane_mode(args.onelane_mode)
+    for e_ in side_engines:
+        e_.set_fork_mode(args.side_fork)      # the second context shares the GPU with the critical path: its CRT halves stay in sequence
 
     def build_parties(window: int) -> tuple[list[PartySet], float, int]:
         """Both parties' scheme objects per shard context.  The fixed-base tables are built once (first context) and shared

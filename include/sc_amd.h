@@ -65,6 +65,12 @@ int sc_ctx_set_onelane_mode(sc_ctx* ctx, int mode);
  * shards of one batch, each on its own stream.  Batch-size policies then count rounds of 1/contexts of the chip (a launch that
  * under-fills the whole chip is not alone on it).  Default 1. */
 int sc_ctx_set_chip_share(sc_ctx* ctx, int contexts);
+/* Fork / join inside one call.  The p- and q-side of the key holder's CRT (sc_paillier_decrypt, sc_paillier_randomize with a secret
+ * key) are independent; when a launch of the batch leaves room for a second one beside it (small batches) the q-side is queued on
+ * a second stream of the context, with its own scratch arena and temporaries, and joined before the recombination.  mode 1
+ * (default): automatic; 0: never (a context that already shares the GPU with another busy one, e.g. the second context that
+ * computes randomizers ahead of time).  Off as well when the latency mode is 0; forced on by latency mode 2 (tests). */
+int sc_ctx_set_fork_mode(sc_ctx* ctx, int mode);
 
 /* device memory helpers for callers that do not bring their own allocator */
 int sc_malloc(sc_ctx* ctx, size_t bytes, void** out_dptr);
@@ -262,7 +268,8 @@ int sc_keyholder_step2_4b(sc_ctx* ctx, int paillier_key, int dgk_key, int l, con
 /* Initiator.step_4c .. step_4i for a batch (SC/initiator.py:272-516): one inversion pass over [d], [beta_i], the fused steps
  * 4c-4h (sc_dgk_step4), then -- when rhos is given -- the blinding c_i^rho_i (:512), the re-randomization * h^r_i when r_rand is
  * given (:153-154) and the shuffle when permutation ([count][l+1] int64, output k takes blinded c at index permutation[b][k]) is
- * given (:516), the last three in ONE launch whose store is the shuffle.  beta: [l][count][nwords] bit-major; rhos / r_rand:
+ * given (:516; a row that is not a permutation of 0 .. l is replaced by the identity), the last three in ONE launch whose store
+ * is the shuffle.  beta: [l][count][nwords] bit-major; rhos / r_rand:
  * [l+1][count][words].  c_unblinded_out (nullable) receives the output of step 4h.  c_out: [l+1][count][nwords]. */
 int sc_initiator_step4(sc_ctx* ctx, int dgk_key, int l, const uint32_t* d_enc_dptr, const uint32_t* beta_enc_dptr,
                        const uint64_t* alpha_dptr, const uint64_t* alpha_tilde_dptr, const uint64_t* rsmall_dptr,

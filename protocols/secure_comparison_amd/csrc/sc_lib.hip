@@ -197,6 +197,7 @@ struct sc_ctx {
   uint32_t* scratch_aux = nullptr;
   size_t scratch_aux_bytes = 0;
   bool in_aux = false;
+  int fork_mode = 1;                                        // sc_ctx_set_fork_mode: 0 never fork inside a call, 1 automatic
   void* scheme_keys = nullptr;                              // Paillier / DGK key objects of the scheme-level entry points (sc_schemes.h)
   bool rng_seeded = false;
   uint64_t rng_call = 0;                                    // generator calls since seeding: part of every keystream's nonce
@@ -260,12 +261,14 @@ int tmp_buf(sc_ctx* ctx, int slot, size_t bytes, void** out) {
   return SC_OK;
 }
 // Fork / join inside one library call.  begin(): everything queued so far on the context's stream happens before the forked work;
-// until end() the context launches on its second stream (own scratch arena, own temporaries); end(): the context's stream waits
-// for the forked work.  Used for the q-side of the key holder's CRT when a launch of the batch leaves most of the chip idle.
+// until suspend() the context launches on its second stream (own scratch arena, own temporaries); after suspend() it is back on
+// its own stream, whose later launches run BESIDE the forked work; join(): the context's stream waits for the forked work.
+// (The forked half is queued first: an event recorded after the other half's launches would wait for them.)
+// Used for the q-side of the key holder's CRT when a launch of the batch leaves most of the chip idle.
 struct AuxFork {
   sc_ctx* ctx = nullptr;
   hipStream_t main = nullptr;
-  bool active = false;
+  bool active = false, pending = false;
   int begin(sc_ctx* c) {
     ctx = c;
     HIPCHK(c, hipSetDevice(c->device));
@@ -282,7 +285,7 @@ struct AuxFork {
     active = true;
     return SC_OK;
   }
-  int end() {
+  int suspend() {
     if (!active) return SC_OK;
     active = false;
     sc_ctx* c = ctx;
@@ -290,15 +293,21 @@ struct AuxFork {
     c->stream = main;
     c->in_aux = false;
     if (e1 != hipSuccess) return fail(c, SC_ERR_HIP, "hipEventRecord: %s", hipGetErrorString(e1));
-    HIPCHK(c, hipStreamWaitEvent(main, c->aux_join, 0));
+    pending = true;
     return SC_OK;
   }
-  ~AuxFork() { (void)end(); }      // error paths: never leave the context on its second stream
+  int join() {
+    int rc = suspend();
+    if (rc) return rc;
+    if (pending) { pending = false; HIPCHK(ctx, hipStreamWaitEvent(main, ctx->aux_join, 0)); }
+    return SC_OK;
+  }
+  ~AuxFork() { (void)join(); }      // error paths: never leave the context on its second stream, nor forked work unordered
 };
 // Is a launch of `count` items of modulus `mod` small enough that a second, independent one fits beside it?  (A wave per SIMD
 // for both: half of the chip's 4 x CUs SIMDs each.)  Off with latency mode 0.
 inline bool small_enough_to_fork(const sc_ctx* ctx, const Mod& m, uint64_t count) {
-  if (ctx->latency_mode == 0 || ctx->in_aux) return false;
+  if (ctx->latency_mode == 0 || ctx->fork_mode == 0 || ctx->in_aux) return false;
   if (ctx->latency_mode == 2) return true;
   const uint64_t per_wave = std::max(1, 64 / (2 * m.G));     // in the small-batch configuration this batch would take
   return (count + per_wave - 1) / per_wave <= (uint64_t)ctx->num_cu * 4 / (uint64_t)ctx->chip_share;
@@ -1481,6 +1490,12 @@ static int onelane_for(sc_ctx* ctx, int mod, uint64_t count) {
 int sc_ctx_set_chip_share(sc_ctx* ctx, int contexts) {
   if (!ctx || contexts < 1 || contexts > 64) return SC_ERR_ARG;
   ctx->chip_share = contexts;
+  return SC_OK;
+}
+
+int sc_ctx_set_fork_mode(sc_ctx* ctx, int mode) {
+  if (!ctx || mode < 0 || mode > 1) return SC_ERR_ARG;
+  ctx->fork_mode = mode;
   return SC_OK;
 }
 

@@ -116,14 +116,25 @@ __global__ void k_select_rows(const uint64_t* __restrict__ flags, const uint32_t
   if (byte_flags && w == 0) byte_flags[i] = (uint8_t)((f ? 1 : 0) ^ invert);
 }
 // the scatter rows of the step-4i shuffle: blinded plane j of comparison b goes to output plane k with perm[b][k] == j, i.e.
-// dest[j * B + b] = k * B + b.  Entries outside 0 .. planes-1 are clamped (the store never leaves the array).
+// dest[j * B + b] = k * B + b.  A row that is not a permutation of 0 .. planes-1 is replaced by the identity, so that EVERY entry
+// of dest is written exactly once per call and the scattered store writes every output row (no fill of either array is needed;
+// the caller learns about such rows from Initiator.permutation_is_valid before anything is sent).  planes <= 128.
 __global__ void k_perm_to_dest(const int64_t* __restrict__ perm, uint64_t* __restrict__ dest, int planes, uint64_t count) {
   const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= count) return;
+  uint64_t seen0 = 0, seen1 = 0;
+  bool ok = true;
   for (int k = 0; k < planes; k++) {
-    int64_t j = perm[b * planes + k];
-    j = j < 0 ? 0 : (j >= planes ? planes - 1 : j);
-    dest[(uint64_t)j * count + b] = (uint64_t)k * count + b;
+    const int64_t j = perm[b * planes + k];
+    if (j < 0 || j >= planes) { ok = false; continue; }
+    uint64_t& word = (j < 64) ? seen0 : seen1;
+    const uint64_t bit = 1ull << (j & 63);
+    ok = ok && !(word & bit);
+    word |= bit;
+  }
+  for (int k = 0; k < planes; k++) {
+    const uint64_t j = ok ? (uint64_t)perm[b * planes + k] : (uint64_t)k;
+    dest[j * count + b] = (uint64_t)k * count + b;
   }
 }
 // bits[plane][b] of the key holder's steps 4a / 4b: plane 0 = d, plane 1 + i = bit i of beta (SC/keyholder.py:213, 230-233)
@@ -151,11 +162,16 @@ int paillier_crt_pow_n(sc_ctx* ctx, const PaillierKey& k, const uint32_t* rho, u
   rc = tmp_words(ctx, TMP_S_C, count * 2 * k.hw, &part_q); if (rc) return rc;
   AuxFork fork;
   const bool forked = small_enough_to_fork(ctx, ctx->mods[k.hp.m1], count);
-  for (int side = 0; side < 2; side++) {
+  for (int pass = 0; pass < 2; pass++) {
+    const int side = forked ? 1 - pass : pass;       // forked: the q-side is queued first, on the second stream, the p-side beside it
     const PaillierHalf& h = side ? k.hq : k.hp;
     uint32_t* part = side ? part_q : part_p;
-    if (side == 1 && forked) {       // the q-side beside the p-side: a small batch leaves room for both
+    if (forked && pass == 0) {
       rc = fork.begin(ctx); if (rc) return rc;
+      rc = tmp_words(ctx, TMP_S_A, count * k.hw, &y); if (rc) return rc;
+    }
+    if (forked && pass == 1) {
+      rc = fork.suspend(); if (rc) return rc;
       rc = tmp_words(ctx, TMP_S_A, count * k.hw, &y); if (rc) return rc;
     }
     rc = sc_modexp_shared(ctx, h.m1, h.exp_small, rho, k.nw, nullptr, y, count); if (rc) return rc;       // wide operand reduced mod p
@@ -166,7 +182,7 @@ int paillier_crt_pow_n(sc_ctx* ctx, const PaillierKey& k, const uint32_t* rho, u
     }
     if (rc) return rc;
   }
-  rc = fork.end(); if (rc) return rc;
+  rc = fork.join(); if (rc) return rc;
   return sc_crt_combine(ctx, k.hp.m2, k.mod_n2, k.r_k, k.r_negk, k.r_mq, part_p, 2 * k.hw, part_q, 2 * k.hw, out, count);
 }
 
@@ -294,10 +310,15 @@ int sc_paillier_decrypt(sc_ctx* ctx, int key, const uint32_t* c, uint32_t* out, 
   rc = tmp_words(ctx, TMP_S_C, count * k.hw, &m_q); if (rc) return rc;
   AuxFork fork;
   const bool forked = small_enough_to_fork(ctx, ctx->mods[k.hp.m1], count);
-  for (int side = 0; side < 2; side++) {
+  for (int pass = 0; pass < 2; pass++) {
+    const int side = forked ? 1 - pass : pass;       // forked: c^(q-1) mod q^2 first, on the second stream; c^(p-1) mod p^2 beside it
     const PaillierHalf& h = side ? k.hq : k.hp;
-    if (side == 1 && forked) {       // c^(q-1) mod q^2 beside c^(p-1) mod p^2
+    if (forked && pass == 0) {
       rc = fork.begin(ctx); if (rc) return rc;
+      rc = tmp_words(ctx, TMP_S_A, count * 2 * k.hw, &x); if (rc) return rc;
+    }
+    if (forked && pass == 1) {
+      rc = fork.suspend(); if (rc) return rc;
       rc = tmp_words(ctx, TMP_S_A, count * 2 * k.hw, &x); if (rc) return rc;
     }
     if (k.pairs && sc_mod_supports_sq(ctx, h.m1) == 1) rc = sc_modexp_shared_sq(ctx, h.m1, h.m2, h.exp_pm1, c, 2 * k.nw, nullptr, x, count);
@@ -305,7 +326,7 @@ int sc_paillier_decrypt(sc_ctx* ctx, int key, const uint32_t* c, uint32_t* out, 
     if (rc) return rc;
     rc = sc_paillier_l_mul(ctx, h.m1, h.cst_h, x, 2 * k.hw, side ? m_q : m_p, count); if (rc) return rc;
   }
-  rc = fork.end(); if (rc) return rc;
+  rc = fork.join(); if (rc) return rc;
   return sc_crt_combine(ctx, k.hp.m1, k.mod_n, k.d_k, k.d_negk, k.d_mq, m_p, k.hw, m_q, k.hw, out, count);
 }
 
@@ -481,9 +502,8 @@ int sc_initiator_step4i(sc_ctx* ctx, int dgk_key_id, int l, const uint32_t* c_in
   if (c_in == c_out) return fail(ctx, SC_ERR_ARG, "sc_initiator_step4i: a shuffled store cannot work in place");
   uint64_t* dest;
   int rc = tmp_words(ctx, TMP_S_H, items, &dest); if (rc) return rc;
-  // rows that no entry names (a row of `permutation` that is not one) stay zero instead of stale memory
-  HIPCHK(ctx, hipMemsetAsync(c_out, 0, items * (size_t)k.nw * 4, ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(dest, 0xff, items * 8, ctx->stream));
+  // (k_perm_to_dest writes every entry of dest -- rows that are not permutations become the identity -- so every output row is
+  // stored; no fill of either array: a runtime fill / copy kernel beside another context's chip-filling launch costs milliseconds)
   hipLaunchKernelGGL(k_perm_to_dest, dim3(blocks_for(count)), dim3(256), 0, ctx->stream, permutation, dest, (int)planes, count);
   HIPCHK(ctx, hipGetLastError());
   return modexp_var_impl(ctx, k.mod_n, c_in, rhos, rho_words, ubits, fbt, e2, r_words, dest, c_out, items, premul);
@@ -565,16 +585,17 @@ int sc_keyholder_step4j_5(sc_ctx* ctx, int paillier_key_id, int dgk_key_id, int 
     return fail(ctx, SC_ERR_ARG, "sc_keyholder_step4j_5: bad argument");
   const PaillierKey p = *pk;
   int rc = sc_dgk_any_zero(ctx, dgk_key_id, c_enc, l + 1, count, delta_b_out); if (rc) return rc;                  // step 4j
-  uint32_t* m3;
-  rc = tmp_words(ctx, TMP_S_E, 3 * count * p.nw, &m3); if (rc) return rc;
-  HIPCHK(ctx, hipMemcpyAsync(m3, zeta1, count * p.nw * 4, hipMemcpyDeviceToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(m3 + count * p.nw, zeta2, count * p.nw * 4, hipMemcpyDeviceToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_u64_to_words, dim3(blocks_for(count * p.nw)), dim3(256), 0, ctx->stream, delta_b_out, m3 + 2 * count * p.nw, p.nw, count);
+  // step 5: three encryptions into the row blocks of one array (no copies of zeta_1 / zeta_2 into a joined plaintext array)
+  uint32_t *db_words, *enc = out3;
+  rc = tmp_words(ctx, TMP_S_E, count * 2, &db_words); if (rc) return rc;
+  hipLaunchKernelGGL(k_u64_to_words, dim3(blocks_for(count * 2)), dim3(256), 0, ctx->stream, delta_b_out, db_words, 2, count);
   HIPCHK(ctx, hipGetLastError());
-  if (!rho3) return sc_paillier_encrypt_raw(ctx, p.mod_n2, p.cst_n, m3, p.nw, out3, 3 * count);                     // step 5, unrandomized
-  uint32_t* enc;
-  rc = tmp_words(ctx, TMP_S_F, 3 * count * 2 * p.nw, &enc); if (rc) return rc;
-  rc = sc_paillier_encrypt_raw(ctx, p.mod_n2, p.cst_n, m3, p.nw, enc, 3 * count); if (rc) return rc;
+  if (rho3) { rc = tmp_words(ctx, TMP_S_F, 3 * count * 2 * p.nw, &enc); if (rc) return rc; }
+  const size_t blk = (size_t)count * 2 * p.nw;
+  rc = sc_paillier_encrypt_raw(ctx, p.mod_n2, p.cst_n, zeta1, p.nw, enc, count); if (rc) return rc;
+  rc = sc_paillier_encrypt_raw(ctx, p.mod_n2, p.cst_n, zeta2, p.nw, enc + blk, count); if (rc) return rc;
+  rc = sc_paillier_encrypt_raw(ctx, p.mod_n2, p.cst_n, db_words, 2, enc + 2 * blk, count); if (rc) return rc;
+  if (!rho3) return SC_OK;                                                                                             // unrandomized
   if (flags & SC_STEP_RANDOMIZERS_READY) return sc_modmul(ctx, p.mod_n2, enc, 2 * p.nw, rho3, 2 * p.nw, out3, 3 * count);   // rho^N computed ahead
   return sc_paillier_randomize(ctx, paillier_key_id, enc, rho3, out3, 3 * count);                                    // the 3 .randomize() (:126-128)
 }

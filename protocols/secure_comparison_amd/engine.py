@@ -770,6 +770,10 @@ class Engine:
         """Large-batch kernel policy for moduli up to 1028 bits (sc_ctx_set_onelane_mode): 0 never, 1 automatic, 2 whenever it fits."""
         self._check(self.lib.sc_ctx_set_onelane_mode(self.ctx, int(mode)))
 
+    def set_fork_mode(self, mode: int) -> None:
+        """Fork / join of the CRT's q-side inside one call on small batches (sc_ctx_set_fork_mode): 0 never, 1 automatic (default)."""
+        self._check(self.lib.sc_ctx_set_fork_mode(self.ctx, int(mode)))
+
     def set_chip_share(self, contexts: int) -> None:
         """This engine shares its GPU with contexts - 1 other engines working at the same time (sc_ctx_set_chip_share)."""
         self._check(self.lib.sc_ctx_set_chip_share(self.ctx, int(contexts)))

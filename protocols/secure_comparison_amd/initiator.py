@@ -292,9 +292,9 @@ class Initiator:
         """Blinding c_i^rho_i (and, when `randomizer_exponents` is given, the `.randomize()` of SC/initiator.py:153-154
         fused in: * h^r_i), then the per-comparison shuffle -- in the store of the same launch (sc_initiator_step4i).
         c_is_enc: [l+1][B][nw]; rhos: [l+1][B][ew]; permutation: [B][l+1] int64 (output k of comparison b takes blinded c at index
-        permutation[b][k]).  Entries are clamped into range inside the library and CHECKED lazily (permutation_is_valid: a device
-        flag the caller reads where it synchronises anyway); the scatter target is zero-filled, so a row that is not a permutation
-        leaves zero planes in that comparison's own vector, never stale device memory."""
+        permutation[b][k]).  A row that is not a permutation of range(l+1) is replaced by the identity inside the library (every
+        output row is written, nothing stale, no other comparison touched) and CHECKED lazily: permutation_is_valid is a device
+        flag the caller reads where it synchronises anyway -- the interactive protocol refuses such input before anything is sent."""
         lp1, count, nw = c_is_enc.shape
         if permutation is not None and (tuple(permutation.shape) != (count, lp1) or permutation.dtype != torch.int64):
             raise ValueError(f"permutation: expected int64 [{count}][{lp1}], got {permutation.dtype} {tuple(permutation.shape)}")

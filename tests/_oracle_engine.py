@@ -166,7 +166,9 @@ class OracleEngine:
         dest = None
         if permutation is not None:
             planes = torch.arange(lp1, dtype=torch.int64).expand(count, lp1)
-            inverse = torch.zeros_like(permutation).scatter_(1, permutation.clamp(0, lp1 - 1), planes)
+            valid = (torch.sort(permutation, dim=1).values == planes).all(dim=1, keepdim=True)
+            permutation = torch.where(valid, permutation, planes)          # a row that is not a permutation: the identity
+            inverse = torch.zeros_like(permutation).scatter_(1, permutation, planes)
             dest = (inverse.t() * count + torch.arange(count, dtype=torch.int64)).reshape(-1)
         if ready and r_rand is not None:        # h^r computed ahead: blind, multiply, then place
             flat = self.modexp_var(key.mod_n, c_in.reshape(lp1 * count, nw), rhos.reshape(lp1 * count, -1), 0)
