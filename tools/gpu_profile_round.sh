@@ -4,7 +4,7 @@
 #   un-profiled bench lines of every BASELINE configuration that fits one GPU.  Output under gpurun_out/$TAG/;
 #   tools/summarize_profiles.py condenses it into profiles/.
 set -o pipefail
-TAG=${1:-r02prof}
+TAG=${1:-r03prof}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
@@ -17,7 +17,8 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU
 done
 echo "== bench lines"
 timeout -k 10 600 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_cfg2_B65536.json 2> $OUT/bench_cfg2.err || exit 1
-timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 --batch 4096 --l 16 --dgk dgk_2048_l16 --no-extras --no-cpu-baseline > $OUT/bench_cfg1_B4096.json 2>> $OUT/bench_other.err || exit 1
+timeout -k 10 300 python3 bench.py --steps 20 --warmup 3 --batch 4096 --l 16 --dgk dgk_2048_l16 --no-extras --no-cpu-baseline > $OUT/bench_cfg1_B4096.json 2>> $OUT/bench_other.err || exit 1
+timeout -k 10 300 python3 bench.py --steps 20 --warmup 3 --batch 4096 --l 16 --dgk dgk_2048_l16 --no-extras --no-cpu-baseline --side-stream 0 > $OUT/bench_cfg1_B4096_one_context.json 2>> $OUT/bench_other.err || exit 1
 timeout -k 10 300 python3 bench.py --steps 6 --warmup 2 --batch 131072 --no-extras --no-cpu-baseline > $OUT/bench_cfg3share_B131072.json 2>> $OUT/bench_other.err || exit 1
 timeout -k 10 300 python3 bench.py --steps 4 --warmup 1 --batch 32768 --l 64 --pbits 3072 --dgk dgk_3072_l64 --no-extras --no-cpu-baseline > $OUT/bench_cfg4share_dgk3072.json 2>> $OUT/bench_other.err || exit 1
 timeout -k 10 300 python3 bench.py --steps 4 --warmup 1 --batch 32768 --l 64 --pbits 3072 --dgk dgk_2048_l64 --no-extras --no-cpu-baseline > $OUT/bench_cfg4share_dgk2048.json 2>> $OUT/bench_other.err || exit 1
