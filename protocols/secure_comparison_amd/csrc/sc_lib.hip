@@ -641,6 +641,7 @@ void sc_ctx_destroy(sc_ctx* ctx) {
   if (ctx->switch_event) (void)hipEventDestroy(ctx->switch_event);
   if (ctx->comm) (void)sc_comm_destroy(ctx);
   if (ctx->scheme_keys) free_scheme_keys(ctx->scheme_keys);
+  memset(&ctx->rng_key, 0, sizeof ctx->rng_key);            // the generator's key does not outlive the context
   delete ctx;
 }
 

@@ -82,6 +82,8 @@ class Engine:
         self._consts: dict[tuple[int, int], int] = {}
         self._crt_k: dict[tuple[int, int], int] = {}          # (m_q, m_p) -> m_q^-1 mod m_p
         self._host_n: dict[tuple[int, int], tuple] = {}       # (n, nwords) -> (array, pointer) kept alive for the plain-word kernels
+        self._pkeys: dict[tuple, "PaillierKey"] = {}          # library-side key objects, one per distinct key and option set:
+        self._dkeys: dict[tuple, "DgkKey"] = {}               # scheme objects come and go (one per session), their keys do not
 
     def close(self) -> None:
         if getattr(self, "ctx", None):
@@ -490,6 +492,9 @@ class Engine:
 
     def paillier_key(self, n: int, p: int | None = None, q: int | None = None, use_crt: bool = True, use_pairs: bool = True) -> PaillierKey:
         """Library-side key object: every modulus / exponent / constant the scheme derives, the key holder's CRT included."""
+        ck = (n, p, q, bool(use_crt), bool(use_pairs))
+        if ck in self._pkeys:
+            return self._pkeys[ck]
         nw = (n.bit_length() + 31) // 32
         pw = 0 if p is None else (max(p.bit_length(), q.bit_length()) + 31) // 32
         a_n, p_n = self._host_words(n, nw)
@@ -499,7 +504,8 @@ class Engine:
         self._sync_stream()
         self._check(self.lib.sc_paillier_key_create(self.ctx, p_n, nw, p_p, p_q, pw, (0 if use_crt else 1) | (0 if use_pairs else 2), C.byref(kid)))
         self._check(self.lib.sc_paillier_key_mods(self.ctx, kid.value, C.byref(m1), C.byref(m2)))
-        return PaillierKey(kid.value, self._mod_handle(m1.value, n, nw), self._mod_handle(m2.value, n * n, 2 * nw), p is not None)
+        self._pkeys[ck] = PaillierKey(kid.value, self._mod_handle(m1.value, n, nw), self._mod_handle(m2.value, n * n, 2 * nw), p is not None)
+        return self._pkeys[ck]
 
     def paillier_encrypt(self, key: PaillierKey, m: torch.Tensor, negate: bool = False, out: torch.Tensor | None = None) -> torch.Tensor:
         count = self._items(m)
@@ -531,12 +537,16 @@ class Engine:
                 v_q: int | None = None, randomizer_bits: int = 400, window: int = 8, use_crt: bool = True,
                 table_source: "tuple[Engine, DgkKey] | None" = None) -> DgkKey:
         """Library-side DGK key object; builds the fixed-base tables for h (or takes `table_source`'s over, read-only)."""
+        ck = (n, g, h, u, t, p, q, v_p, v_q, int(randomizer_bits), int(window), bool(use_crt))
+        if ck in self._dkeys:          # the same key, tables included, whoever asks (and wherever its tables came from)
+            return self._dkeys[ck]
         nw, uw = (n.bit_length() + 31) // 32, (u.bit_length() + 31) // 32
         pw = 0 if p is None else (max(p.bit_length(), q.bit_length()) + 31) // 32
         vw = 0 if v_p is None else (max(v_p.bit_length(), v_q.bit_length()) + 31) // 32
         keep = [self._host_words(x, nw) for x in (n, g % n, h % n)] + [self._host_words(u, uw)]
         sec = [self._words_arg(x, w) for x, w in ((p, pw), (q, pw), (v_p, vw), (v_q, vw))]
         if table_source is not None and table_source[0] is self:
+            self._dkeys[ck] = table_source[1]
             return table_source[1]
         src_ctx, src_key = (C.c_void_p(0), -1) if table_source is None else (table_source[0].ctx, table_source[1].id)
         kid, m_n, m_p = C.c_int(), C.c_int(), C.c_int()
@@ -546,7 +556,8 @@ class Engine:
                                                C.byref(kid)))
         self._check(self.lib.sc_dgk_key_info(self.ctx, kid.value, C.byref(m_n), C.byref(m_p), None))
         mod_p = None if p is None else self._mod_handle(m_p.value, p, (p.bit_length() + 31) // 32)
-        return DgkKey(kid.value, self._mod_handle(m_n.value, n, nw), mod_p, u, int(randomizer_bits), int(window), p is not None)
+        self._dkeys[ck] = DgkKey(kid.value, self._mod_handle(m_n.value, n, nw), mod_p, u, int(randomizer_bits), int(window), p is not None)
+        return self._dkeys[ck]
 
     def dgk_table_bytes(self, key: DgkKey) -> int:
         v = C.c_uint64()

@@ -4,7 +4,7 @@ import json, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 import bench
-from protocols.secure_comparison_amd import DGK, Paillier
+from protocols.secure_comparison_amd import DGK, Initiator, Paillier
 from protocols.secure_comparison_amd.schemes import default_engine
 
 B, l, rbits = 65536, 32, 400
@@ -28,8 +28,9 @@ for w in (16, 20):
         print(f"w={w}  {name:52s} {e0.elapsed_time(e1):8.2f} ms", flush=True)
     t("fixed base h^r (Alice, mod n), random exponents", lambda: alice_d.randomize_batch(None, e_rand))
     t("fixed base h^r (Alice, mod n), zero exponents", lambda: alice_d.randomize_batch(None, torch.zeros_like(e_rand)))
-    t("blind c^rho * h^r, random rho, random r", lambda: eng.modexp_var(alice_d.mod_n, c33, rho, 35, alice_d.fb_h, e_rand))
-    t("blind c^rho * h^r, random rho, zero r", lambda: eng.modexp_var(alice_d.mod_n, c33, rho, 35, alice_d.fb_h, torch.zeros_like(e_rand)))
+    c33p = c33.reshape(l + 1, B, -1)
+    t("blind c^rho * h^r, random rho, random r", lambda: Initiator.step_4i_batch(c33p, alice_d, draws.rhos, None, draws.r_alice_dgk))
+    t("blind c^rho * h^r, random rho, zero r", lambda: Initiator.step_4i_batch(c33p, alice_d, draws.rhos, None, torch.zeros_like(draws.r_alice_dgk)))
     t("blind c^rho only (no fixed base)", lambda: eng.modexp_var(alice_d.mod_n, c33, rho, 35))
     t("bob h^r CRT (mod p, q tables), random", lambda: bob_d.randomize_batch(None, draws.r_bob_dgk.reshape((l + 1) * B, -1)))
     t("bob h^r CRT, zero exponents", lambda: bob_d.randomize_batch(None, torch.zeros_like(e_rand)))
