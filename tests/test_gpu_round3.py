@@ -331,3 +331,52 @@ def test_randomizers_on_a_second_stream_give_the_same_residues(engine, keys, B, 
     idx = [0, 1, B // 2, B - 1]
     assert engine.download(split[torch.tensor(idx, device=engine.device)]) == _oracle_rows(engine, idx, l, sk, dgk, x_enc, y_enc, draws)
     e2.close()
+
+
+def test_interactive_protocol_on_device_draws_is_bit_exact_for_sampled_rows(engine, keys):
+    """The whole chain that nobody injects anything into: perform_secure_comparison_batch with draws=None at l = 32 / 2048-bit
+    keys / B = 4096, the engine's generator keyed with a known key.  The draws of SAMPLED comparisons are restated on the CPU from
+    the key alone (oracle/chacha_rng.py: every item has its own keystream; Alice's six generator calls come first, then the key
+    holder's two) and fed to oracle.compare: the GPU's results for those rows must equal the oracle's bit for bit."""
+    sys.path.insert(0, os.path.dirname(__file__))
+    import bench
+    from _comm import DictionaryCommunicator
+    from oracle import sc_oracle as o
+    from protocols.secure_comparison_amd import Initiator, KeyHolder
+
+    sk, dgk = oracle_paillier(keys, 2048), oracle_dgk(keys, "dgk_2048_l32")
+    B, l, rbits = 4096, 32, 400
+    alice_p, alice_d, bob_p, bob_d = _schemes(engine, sk, dgk, rbits)
+    x, y, x_enc, y_enc, _ = bench.synth_inputs(engine, l, alice_p, bob_p, bob_d, B, rbits, seed=33)
+    box = {}
+    alice = Initiator(l, DictionaryCommunicator(box), "bob")
+    bob = KeyHolder(l, DictionaryCommunicator(box), "alice", bob_p, bob_d)
+
+    async def go():
+        res, _ = await asyncio.gather(alice.perform_secure_comparison_batch(x_enc, y_enc, engine=engine), bob.perform_secure_comparison_batch())
+        return res
+
+    engine.rng_seed(KEY)
+    res = asyncio.run(go())
+    dec = bob_p.decrypt_raw_batch(res)
+    assert bool(((dec[:, 0] == (x <= y).to(torch.int32)) & (dec[:, 1:] == 0).all(dim=1)).all().item())
+    idx = [0, 1, 63, 64, 511, 512, 513, B // 2, B - 65, B - 1]
+    n, u, lp1 = sk.n, dgk.u, l + 1
+    planes = lambda b: [i * B + b for i in range(lp1)]                                    # noqa: E731  (bit-major item indices)
+    r = cr.rng_below(KEY, 0, n, B, items=idx)
+    delta_a = cr.rng_coins(KEY, 1, B, items=idx)
+    rhos = [cr.rng_below(KEY, 2, u, lp1 * B, nonzero=True, items=planes(b)) for b in idx]
+    perms = cr.rng_permutations(KEY, 3, lp1, B, items=idx)
+    rho_z = cr.rng_below(KEY, 4, n, B, nonzero=True, items=idx)
+    r_alice = [cr.rng_bits(KEY, 5, rbits, lp1 * B, items=planes(b)) for b in idx]
+    rho3 = [cr.rng_below(KEY, 6, n, 3 * B, nonzero=True, items=[b, B + b, 2 * B + b]) for b in idx]
+    r_bob = [cr.rng_bits(KEY, 7, rbits, lp1 * B, items=planes(b)) for b in idx]
+    xs, ys = engine.download(x_enc[torch.tensor(idx, device=engine.device)]), engine.download(y_enc[torch.tensor(idx, device=engine.device)])
+    expect = []
+    for k in range(len(idx)):
+        pm = perms[k]
+        rc = [r_alice[k][src] for src in pm]       # the library randomizes c_j with r_alice[j] before the shuffle, the oracle output k after it
+        dr = o.Draws(r=r[k], delta_a=delta_a[k], rhos=rhos[k], perm=pm, rho_z=rho_z[k], r_d=r_bob[k][0], r_beta=r_bob[k][1:], r_c=rc,
+                     rho_zeta1=rho3[k][0], rho_zeta2=rho3[k][1], rho_delta_b=rho3[k][2])
+        expect.append(o.compare(xs[k], ys[k], l, sk, dgk, dr, True))
+    assert engine.download(res[torch.tensor(idx, device=engine.device)]) == expect
