@@ -126,15 +126,7 @@ const Config kOneLane = {1, 37, 28, false};
 // of the CU -- 2.6x a squaring instead of 1.4x, a net loss of 12 % on x^p mod p^2; the one-lane form is used where it wins:
 // the single-modulus exponentiations)
 // (8,5) / (16,5): the SMALL-BATCH pair configurations of 1024 / 2048-bit moduli (kLatencyPair below)
-// (2,28) / (4,28) with 28-bit limbs: the pair configurations of 1536 / 3072-bit moduli (kPair28 below)
-inline bool pair_capable(int G, int L, int W) {
-  return (W == 29 && (L == 18 || (L == 14 && (G == 4 || G == 8)) || (L == 5 && (G == 8 || G == 16)))) || (W == 28 && L == 28 && (G == 2 || G == 4));
-}
-// Moduli of 1536 / 3072 bits (configs[4]: 3072-bit Paillier N and its primes) have L = 27 as their own configuration, which the pair
-// arithmetic cannot use (three products per column need 3 L 2^(2W) < 2^64: L <= 21 at W = 29).  Round 2 ran their pair launches in
-// (4,14) / (8,14) twins -- 78-85 % multiply-adds per limb step.  With 28-bit limbs the bound allows L = 28 (84 * 2^56 < 2^64) at the
-// SAME S = 56 / 112 limbs: (2,28) / (4,28), 88-92 % multiply-adds per step, half the lanes per number.
-const Config kPair28_2 = {2, 28, 28, false}, kPair28_4 = {4, 28, 28, false};
+inline bool pair_capable(int G, int L, int W) { return W == 29 && (L == 18 || (L == 14 && (G == 4 || G == 8)) || (L == 5 && (G == 8 || G == 16))); }
 // Small batches of pair exponentiations (Alice's rho^N mod N^2, the key holder's c^(p-1) mod p^2 at B = 4096) are one dependent
 // chain of ~2400 pair squarings per item, and a wave's time per squaring is its own instruction count: S limb steps of
 // (L + L/2) multiply-adds + ~7 bookkeeping instructions each, whatever the number of lanes.  When even the (2G, 9) form
@@ -549,10 +541,6 @@ int run_pvm(sc_ctx* ctx, int mod, const Prog& p, const VmExt* exts, int next, ui
   if (m.L == 5) switch (m.G) {
     case 8: return launch_pvm_cfg<8, 5>(ctx, a);
     case 16: return launch_pvm_cfg<16, 5>(ctx, a);
-  }
-  if (m.L == 28 && m.W == 28) switch (m.G) {
-    case 2: return launch_pvm_cfg<2, 28, 28>(ctx, a);
-    case 4: return launch_pvm_cfg<4, 28, 28>(ctx, a);
   }
   return fail(ctx, SC_ERR_UNSUPPORTED, "no pair kernel for G=%d", m.G);
 }
@@ -1447,15 +1435,8 @@ static int pair_twin(sc_ctx* ctx, int mod) {
   auto it = ctx->pair_twins.find(mod);
   if (it != ctx->pair_twins.end()) return it->second;
   const Big n = ctx->mods[mod].n;
-  const int nbits = ctx->mods[mod].nbits, nwords = ctx->mods[mod].nwords;
   int twin = -1;
-  static const bool pair28 = []{ const char* e = getenv("SC_PAIR28"); return !(e && e[0] == '0'); }();   // A/B switch (dev): SC_PAIR28=0 -> the L = 14 twins
-  for (const Config* c : {&kPair28_2, &kPair28_4}) {
-    const int cap = c->W * c->G * c->L;
-    if (pair28 && twin < 0 && nbits + 8 <= cap && 32 * nwords <= cap && nbits > 29 * c->G * 18 - 8)    // only where L = 18 does not fit
-      if (create_mod(ctx, n.data(), (int)n.size(), false, &twin, c) != SC_OK) twin = -1;
-  }
-  if (twin < 0 && create_mod(ctx, n.data(), (int)n.size(), true, &twin) != SC_OK) twin = -1;
+  if (create_mod(ctx, n.data(), (int)n.size(), true, &twin) != SC_OK) twin = -1;
   ctx->pair_twins[mod] = twin;
   return twin;
 }
