@@ -1,0 +1,85 @@
+"""The batched interactive protocol between TWO PROCESSES (the reference's integration test runs its two players over an HTTP
+pool pair, SC/test/integration/test_pool.py:41-73): Alice in this process, the key holder in a child process, every message a
+byte string over a multiprocessing pipe -- so nothing but the documented wire format (wire.py) crosses, and the draws of each
+party come from its own generator.  Arithmetic by the test-only OracleEngine (no GPU in this tier)."""
+import asyncio
+import multiprocessing as mp
+import os
+import random
+import sys
+
+import pytest
+
+from conftest import ROOT, oracle_dgk, oracle_paillier
+
+L = 16
+
+
+class PipeCommunicator:
+    """Bytes only: (msg_id, payload) frames over a duplex pipe; messages that arrive early wait in a local mailbox."""
+
+    device_tensors = False
+
+    def __init__(self, conn):
+        self.conn, self.box = conn, {}
+
+    async def send(self, party_id, message, msg_id):
+        payload = bytes(message)                    # a memoryview from wire.pack_many, or the JSON scheme document
+        self.conn.send_bytes(msg_id.encode() + b"\0" + payload)
+
+    async def recv(self, party_id, msg_id):
+        while msg_id not in self.box:
+            if not self.conn.poll(60):
+                raise TimeoutError(msg_id)
+            frame = self.conn.recv_bytes()
+            key, _, payload = frame.partition(b"\0")
+            self.box[key.decode()] = payload
+        return self.box.pop(msg_id)
+
+
+def _keyholder_process(conn, root):
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import json
+
+    from _oracle_engine import OracleEngine
+    from conftest import oracle_dgk as od_, oracle_paillier as op_
+    from protocols.secure_comparison_amd import DGK, KeyHolder, Paillier
+
+    keys = json.load(open(os.path.join(root, "tests", "golden", "keys.json")))
+    osk, od = op_(keys, 1024), od_(keys, "dgk_tiny_l16")
+    eng = OracleEngine()
+    bob = KeyHolder(L, PipeCommunicator(conn), "alice", Paillier(osk.n, osk.p, osk.q, engine=eng),
+                    DGK(od.n, od.g, od.h, od.u, od.t, od.p, od.q, od.v_p, od.v_q, engine=eng, randomizer_bits=50))
+    for _ in range(2):
+        asyncio.run(bob.perform_secure_comparison_batch())
+    conn.close()
+
+
+def test_two_processes_bytes_only(keys):
+    from _oracle_engine import OracleEngine
+    from protocols.secure_comparison_amd import Initiator
+
+    osk, od = oracle_paillier(keys, 1024), oracle_dgk(keys, "dgk_tiny_l16")
+    ctx = mp.get_context("spawn")
+    here, there = ctx.Pipe(duplex=True)
+    child = ctx.Process(target=_keyholder_process, args=(there, ROOT), daemon=True)
+    child.start()
+    try:
+        eng = OracleEngine()
+        alice = Initiator(L, PipeCommunicator(here), "bob")
+        rng = random.Random(17)
+        nw = 32
+        for B in (6, 1):                             # two sessions on one connection: the session-numbered labels keep them apart
+            xs = [rng.randrange(1 << L) for _ in range(B)]
+            ys = [xs[i] if i % 3 == 0 else rng.randrange(1 << L) for i in range(B)]
+            tx = eng.upload([osk.randomize(osk.enc_raw(x), 1 + rng.randrange(osk.n - 1)) for x in xs], 2 * nw)
+            ty = eng.upload([osk.randomize(osk.enc_raw(y), 1 + rng.randrange(osk.n - 1)) for y in ys], 2 * nw)
+            res = asyncio.run(alice.perform_secure_comparison_batch(tx, ty, engine=eng))
+            assert [osk.dec_raw(v) for v in eng.download(res)] == [int(x <= y) for x, y in zip(xs, ys)]
+        assert alice.session_id == 2 and alice.scheme_paillier.public_key.n == osk.n and alice.scheme_paillier.secret_key is None
+    finally:
+        child.join(30)
+        if child.is_alive():
+            child.kill()
+    assert child.exitcode == 0
