@@ -242,7 +242,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-crt", action="store_true")
     ap.add_argument("--no-shuffle", action="store_true", help="leave the step-4i permutation out (do_shuffle=False)")
     ap.add_argument("--streams", type=int, default=0, help="concurrent shards per GPU (one library context, HIP stream and host thread each); 1 = a single stream; "
-                    "0 = automatic: 2 from 65536 comparisons per GPU")
+                    "0 = automatic: 2 from 32768 comparisons of 2048-bit keys per GPU (scaled by the square of the key size)")
     ap.add_argument("--side-stream", type=int, default=-1, help="run the randomizer exponentiations of a step on a second library context and stream per shard, "
                     "concurrently with the protocol's critical path (batch._AheadOfTime): 1 on, 0 off, -1 automatic (on up to 8192 comparisons per GPU: measured +15 % at 4096, -2 % at 16384)")
     ap.add_argument("--side-fork", type=int, default=0, help="fork mode (sc_ctx_set_fork_mode) of the second contexts")
@@ -303,7 +303,9 @@ def main() -> None:
     H = lambda name: int(dj[name], 16)  # noqa: E731
     use_crt = not args.no_crt
     eng = default_engine()
-    ns = max(1, min(args.streams, B)) if args.streams > 0 else (2 if B >= 65536 else 1)
+    # two concurrent shards pay from about 32768 comparisons of 2048-bit keys per GPU (+1.4 % there, +5 % at 65536, +7 % at the
+    # 3072-bit configs[4] share of 32768); the weight of a comparison grows with the square of the key size
+    ns = max(1, min(args.streams, B)) if args.streams > 0 else (2 if B * (args.pbits / 2048.0) ** 2 >= 32768 else 1)
     ns = launcher.host_threads_per_rank(world, ns)      # shard threads of all ranks together stay within the node's cores
     use_side = bool(args.side_stream) if args.side_stream >= 0 else (B <= 8192)
     engines = [eng] + [Engine() for _ in range(1, ns)]
