@@ -218,6 +218,14 @@ int sc_dgk_step4(sc_ctx* ctx, int mod, int cst_g, int cst_ginv, int l, const uin
  * path runs (the reference pre-generates its randomizers in background workers: boot_randomness_generation,
  * SC/initiator.py:205-210, SC/keyholder.py:174-179).  The step then applies them with one modular product each. */
 #define SC_STEP_RANDOMIZERS_READY 1
+/* SC_STEP_DEFER_CHECKS: the step's modular inversion (sc_initiator_step1 / _step4 / _step67) does not wait for its verdict --
+ * no host round trip in the middle of a protocol step, the whole step is queued ahead of the GPU.  The caller must call
+ * sc_ctx_check before trusting the outputs (one synchronisation for all pending inversions; a non-invertible element is named as
+ * by sc_modinv: the failing inversion is repeated with its verdicts read at once, so the step's INPUT arrays must be intact until
+ * then).  Without the flag a step reports a non-invertible element itself (SC_ERR_NOT_INVERTIBLE).  For drivers that run both
+ * parties in one process; a party that is about to SEND a step's output checks first. */
+#define SC_STEP_DEFER_CHECKS 2
+int sc_ctx_check(sc_ctx* ctx, int64_t* bad_index /* nullable */);
 int sc_paillier_key_create(sc_ctx* ctx, const uint32_t* n_hptr, int nwords, const uint32_t* p_hptr /* nullable */,
                            const uint32_t* q_hptr /* nullable */, int pwords, int flags, int* out_key);
 /* the primitive handles behind a key (for callers that mix scheme-level and primitive calls) */
@@ -289,7 +297,7 @@ int sc_keyholder_step4j_5(sc_ctx* ctx, int paillier_key, int dgk_key, int l, con
 /* Initiator.step_6 + step_7 (SC/initiator.py:518-564) with one inversion pass: out = [[x <= y]], not randomized. */
 int sc_initiator_step67(sc_ctx* ctx, int paillier_key, const uint64_t* delta_a_dptr, const uint32_t* delta_b_enc_dptr,
                         const uint32_t* zeta1_enc_dptr, const uint32_t* zeta2_enc_dptr, const uint64_t* rsmall_dptr,
-                        const uint32_t* rshift_dptr, uint32_t* out_dptr, uint64_t count);
+                        const uint32_t* rshift_dptr, int flags, uint32_t* out_dptr, uint64_t count);
 
 /* ---- device-side CSPRNG: the random draws of a batch, generated where they are consumed ---------------- */
 /* The reference draws from Python's `secrets` (SC/initiator.py:223 permutation, :250 r, :420 delta_A, :512 rho_i) and the

@@ -16,7 +16,7 @@ SYMBOLS = [
     "sc_modinv", "sc_paillier_encrypt_raw", "sc_paillier_encrypt_raw_neg", "sc_paillier_l_mul", "sc_crt_combine", "sc_plain_alice", "sc_plain_bob", "sc_dgk_step4",
     "sc_paillier_key_create", "sc_paillier_key_mods", "sc_paillier_encrypt", "sc_paillier_randomize", "sc_paillier_decrypt",
     "sc_dgk_key_create", "sc_dgk_key_info", "sc_dgk_randomize", "sc_dgk_encrypt_bits_randomized", "sc_dgk_is_zero", "sc_dgk_any_zero",
-    "sc_initiator_step1", "sc_keyholder_step2_4b", "sc_initiator_step4", "sc_initiator_step4i", "sc_keyholder_step4j_5", "sc_initiator_step67",
+    "sc_initiator_step1", "sc_keyholder_step2_4b", "sc_initiator_step4", "sc_initiator_step4i", "sc_keyholder_step4j_5", "sc_initiator_step67", "sc_ctx_check",
     "sc_rng_seed", "sc_rng_bits", "sc_rng_below", "sc_rng_coins", "sc_rng_permutations",
     "sc_peak_probe", "sc_mac_counter", "sc_table_traffic_probe", "sc_ctx_set_latency_mode", "sc_ctx_set_onelane_mode", "sc_ctx_set_chip_share", "sc_ctx_set_fork_mode", "sc_comm_unique_id", "sc_comm_init", "sc_allgather", "sc_comm_destroy",
 ]
@@ -98,7 +98,8 @@ def load() -> C.CDLL:
         "sc_initiator_step4": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, u64]),
         "sc_initiator_step4i": (i32, [vp, i32, i32, vp, vp, i32, vp, vp, i32, i32, vp, u64]),
         "sc_keyholder_step4j_5": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, u64]),
-        "sc_initiator_step67": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, u64]),
+        "sc_initiator_step67": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, u64]),
+        "sc_ctx_check": (i32, [vp, i64p]),
         "sc_rng_seed": (i32, [vp, vp]),
         "sc_rng_bits": (i32, [vp, i32, vp, u64]),
         "sc_rng_below": (i32, [vp, vp, i32, i32, vp, u64]),

@@ -136,16 +136,17 @@ def secure_comparison_batch(x_enc: torch.Tensor, y_enc: torch.Tensor, l: int, al
     if side is not None and randomize:
         ahead = _AheadOfTime(side, draws, l)
         count = x_enc.shape[0]
-        z_enc, a_plain = Initiator.step_1_batch(x_enc, y_enc, l, alice_paillier, draws.r, None)
+        z_enc, a_plain = Initiator.step_1_batch(x_enc, y_enc, l, alice_paillier, draws.r, None, defer_checks=True)
         z_enc = alice_paillier.add_batch(z_enc, ahead.take("rz"))
         b_plain, d_enc, beta_enc = KeyHolder.step_2_4b_batch(z_enc, l, bob_paillier, bob_dgk,
                                                              ahead.take("hr_bob").reshape(l + 1, count, -1), randomizers_ready=True)
         c_sent, c_h = Initiator.step_4_batch(d_enc, beta_enc, a_plain, draws.delta_a, alice_dgk, draws.rhos, draws.permutation,
                                              ahead.take("hr_alice").reshape(l + 1, count, -1), want_unblinded=trace is not None,
-                                             randomizers_ready=True)
+                                             randomizers_ready=True, defer_checks=True)
         delta_b, zeta_1_enc, zeta_2_enc, delta_b_enc = KeyHolder.step_4j_5_batch(c_sent, b_plain, bob_paillier, bob_dgk, ahead.take("r3"),
                                                                                  randomizers_ready=True)
-        result = Initiator.step_6_7_batch(draws.delta_a, delta_b_enc, zeta_1_enc, zeta_2_enc, a_plain, l, alice_paillier)
+        result = Initiator.step_6_7_batch(draws.delta_a, delta_b_enc, zeta_1_enc, zeta_2_enc, a_plain, l, alice_paillier, defer_checks=True)
+        _check_engines(alice_paillier, alice_dgk)
         if trace is not None:
             trace.z_enc, trace.z, trace.d_enc, trace.beta_enc = z_enc, b_plain.z, d_enc, beta_enc
             trace.c_step4h, trace.c_sent, trace.delta_b = c_h, c_sent, delta_b
@@ -153,22 +154,36 @@ def secure_comparison_batch(x_enc: torch.Tensor, y_enc: torch.Tensor, l: int, al
         return result
     # five library calls per batch (include/sc_amd.h, scheme-level entry points)
     # Alice: steps 1, 3 (+ the randomization of [[z]])
-    z_enc, a_plain = Initiator.step_1_batch(x_enc, y_enc, l, alice_paillier, draws.r, draws.rho_z if randomize else None)
+    # (no host round trip inside the step: the three inversions' verdicts are read together at the end, batch-driver only --
+    # a party of the interactive protocol checks before it sends)
+    z_enc, a_plain = Initiator.step_1_batch(x_enc, y_enc, l, alice_paillier, draws.r, draws.rho_z if randomize else None, defer_checks=True)
     # Bob: steps 2, 4a, 4b (+ l + 1 randomizations)
     b_plain, d_enc, beta_enc = KeyHolder.step_2_4b_batch(z_enc, l, bob_paillier, bob_dgk, draws.r_bob_dgk if randomize else None)
     # Alice: steps 4c-4i (+ l + 1 randomizations, shuffle)
     c_sent, c_h = Initiator.step_4_batch(d_enc, beta_enc, a_plain, draws.delta_a, alice_dgk, draws.rhos, draws.permutation,
-                                         draws.r_alice_dgk if randomize else None, want_unblinded=trace is not None)
+                                         draws.r_alice_dgk if randomize else None, want_unblinded=trace is not None, defer_checks=True)
     # Bob: steps 4j, 5 (+ 3 randomizations)
     rho3 = cat_rows([draws.rho_zeta_1, draws.rho_zeta_2, draws.rho_delta_b]) if randomize else None   # three blocks of one array: a view
     delta_b, zeta_1_enc, zeta_2_enc, delta_b_enc = KeyHolder.step_4j_5_batch(c_sent, b_plain, bob_paillier, bob_dgk, rho3)
     # Alice: steps 6, 7
-    result = Initiator.step_6_7_batch(draws.delta_a, delta_b_enc, zeta_1_enc, zeta_2_enc, a_plain, l, alice_paillier)
+    result = Initiator.step_6_7_batch(draws.delta_a, delta_b_enc, zeta_1_enc, zeta_2_enc, a_plain, l, alice_paillier, defer_checks=True)
+    _check_engines(alice_paillier, alice_dgk)
     if trace is not None:
         trace.z_enc, trace.z, trace.d_enc, trace.beta_enc = z_enc, b_plain.z, d_enc, beta_enc
         trace.c_step4h, trace.c_sent, trace.delta_b = c_h, c_sent, delta_b
         trace.zeta_1_enc, trace.zeta_2_enc, trace.delta_b_enc = zeta_1_enc, zeta_2_enc, delta_b_enc
     return result
+
+
+def _check_engines(*schemes) -> None:
+    """Read the deferred inversion verdicts of the engines behind `schemes` (one synchronisation each; usually one engine)."""
+    seen = []
+    for s in schemes:
+        e = s.engine
+        if all(e is not o for o in seen):
+            seen.append(e)
+            if hasattr(e, "check"):
+                e.check()
 
 
 def _secure_comparison_batch_pooled(x_enc, y_enc, l, alice_paillier, alice_dgk, bob_paillier, bob_dgk, draws: BatchDraws) -> torch.Tensor:

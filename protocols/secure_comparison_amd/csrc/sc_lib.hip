@@ -197,6 +197,9 @@ struct sc_ctx {
   uint32_t* scratch_aux = nullptr;
   size_t scratch_aux_bytes = 0;
   bool in_aux = false;
+  struct DeferredInv { int mod; const uint32_t* x; uint64_t count; int* d_status; uint64_t top_count; };
+  std::vector<DeferredInv> deferred;                        // inversions whose verdicts have not been read yet (sc_ctx_check)
+  int status_slot_override = -1;                            // the status buffer of a deferred inversion must outlive the call
   int fork_mode = 1;                                        // sc_ctx_set_fork_mode: 0 never fork inside a call, 1 automatic
   void* scheme_keys = nullptr;                              // Paillier / DGK key objects of the scheme-level entry points (sc_schemes.h)
   bool rng_seeded = false;
@@ -313,7 +316,8 @@ inline bool small_enough_to_fork(const sc_ctx* ctx, const Mod& m, uint64_t count
   return (count + per_wave - 1) / per_wave <= (uint64_t)ctx->num_cu * 4 / (uint64_t)ctx->chip_share;
 }
 
-enum TmpSlot { TMP_PARK = 1, TMP_XGCD_STATUS = 2, TMP_CRT = 3, TMP_PAIR = 4, TMP_INV_MEMBERS = 5, TMP_INV_BASE = 16 /* + 2*depth, + 2*depth+1 */ };
+enum TmpSlot { TMP_PARK = 1, TMP_XGCD_STATUS = 2, TMP_CRT = 3, TMP_PAIR = 4, TMP_INV_MEMBERS = 5, TMP_DEFER_OUT = 6, TMP_INV_BASE = 16 /* + 2*depth, + 2*depth+1 */,
+               TMP_DEFER_STATUS = 200 /* + index of the pending inversion */ };
 
 // device copy of n | (n-1)/2 as canonical words (plain-word kernels)
 int device_n_half(sc_ctx* ctx, const uint32_t* n_hptr, int nw, uint32_t** out) {
@@ -1148,7 +1152,7 @@ static int modinv_rec(sc_ctx* ctx, int mod, const uint32_t* x, uint32_t* out, ui
   const uint64_t TOP = SC_INV_TOP;
   if (count <= TOP) {
     int* d_status;
-    { int rc0 = tmp_buf(ctx, TMP_XGCD_STATUS, sizeof(int) * count, (void**)&d_status); if (rc0) return rc0; }
+    { int rc0 = tmp_buf(ctx, ctx->status_slot_override >= 0 ? ctx->status_slot_override : TMP_XGCD_STATUS, sizeof(int) * count, (void**)&d_status); if (rc0) return rc0; }
     uint32_t* d_nw = nullptr;
     { int rc0 = device_n_half(ctx, m.n.data(), m.nwords, &d_nw); if (rc0) return rc0; }
     int rc = launch_xgcd(ctx->stream, x, out, d_nw, m.nwords, count, d_status);
@@ -1261,6 +1265,51 @@ int sc_modinv(sc_ctx* ctx, int mod, const uint32_t* x, uint32_t* out, uint64_t c
   }
   if (bad_index) *bad_index = bad;
   return fail(ctx, SC_ERR_NOT_INVERTIBLE, "element %lld is not invertible", (long long)bad);
+}
+
+// Queue an inversion WITHOUT reading its verdicts: no host round trip in the middle of a protocol step.  The verdict words stay on
+// the device (a buffer of their own per pending inversion) until sc_ctx_check reads them all at once; a non-invertible element
+// makes the outputs garbage numbers (never an out-of-bounds access) that flow through the rest of the step and are discarded when
+// the check fails.  x must stay intact until the check (it names the bad element by running the inversion again, synchronously).
+static int modinv_deferred(sc_ctx* ctx, int mod, const uint32_t* x, uint32_t* out, uint64_t count) {
+  if (count == 0) return SC_OK;
+  if (ctx->deferred.size() >= 32) return fail(ctx, SC_ERR_ARG, "too many unchecked inversions: call sc_ctx_check");
+  InvPending pend;
+  ctx->status_slot_override = TMP_DEFER_STATUS + (int)ctx->deferred.size();
+  const int rc = modinv_rec(ctx, mod, x, out, count, &pend, 0);
+  ctx->status_slot_override = -1;
+  if (rc) return rc;
+  ctx->deferred.push_back(sc_ctx::DeferredInv{mod, x, count, pend.d_status, pend.top_count});
+  return SC_OK;
+}
+
+int sc_ctx_check(sc_ctx* ctx, int64_t* bad_index) {
+  if (!ctx) return SC_ERR_ARG;
+  if (bad_index) *bad_index = -1;
+  if (ctx->deferred.empty()) return SC_OK;
+  std::vector<sc_ctx::DeferredInv> pending;
+  pending.swap(ctx->deferred);
+  std::vector<std::vector<int>> st(pending.size());
+  for (size_t i = 0; i < pending.size(); i++) {
+    st[i].resize(pending[i].top_count);
+    HIPCHK(ctx, hipMemcpyAsync(st[i].data(), pending[i].d_status, sizeof(int) * pending[i].top_count, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));          // the one host round trip of the step
+  for (size_t i = 0; i < pending.size(); i++) {
+    bool bad = false;
+    for (int v : st[i]) bad = bad || v != 1;
+    if (!bad) continue;
+    // name the element: the same inversion again, with the verdicts read at once (the operands are still there)
+    const sc_ctx::DeferredInv& d = pending[i];
+    uint32_t* scratch_out;
+    { int rc0 = tmp_buf(ctx, TMP_DEFER_OUT, (size_t)d.count * ctx->mods[d.mod].nwords * 4, (void**)&scratch_out); if (rc0) return rc0; }
+    int64_t idx = -1;
+    const int rc = sc_modinv(ctx, d.mod, d.x, scratch_out, d.count, &idx);
+    if (bad_index) *bad_index = idx;
+    if (rc == SC_ERR_NOT_INVERTIBLE) return fail(ctx, rc, "element %lld of unchecked inversion %d of this step is not invertible", (long long)idx, (int)i);
+    return rc ? rc : fail(ctx, SC_ERR_HIP, "an unchecked inversion failed but its repetition did not");
+  }
+  return SC_OK;
 }
 
 int sc_dgk_step4(sc_ctx* ctx, int mod, int cst_g, int cst_ginv, int l, const uint32_t* beta, const uint32_t* beta_inv,

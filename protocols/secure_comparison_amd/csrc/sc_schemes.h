@@ -475,7 +475,8 @@ int sc_initiator_step1(sc_ctx* ctx, int paillier_key_id, int l, const uint32_t* 
   rc = tmp_words(ctx, TMP_S_G, count * 2 * k.nw, &t); if (rc) return rc;
   rc = sc_plain_alice(ctx, r, k.n.data(), k.nw, l, count, m1, alpha, alpha_tilde, rsmall, rshift); if (rc) return rc;
   int64_t bad = -1;
-  rc = sc_modinv(ctx, k.mod_n2, x_enc, xinv, count, &bad); if (rc) return rc;
+  rc = (flags & SC_STEP_DEFER_CHECKS) ? modinv_deferred(ctx, k.mod_n2, x_enc, xinv, count) : sc_modinv(ctx, k.mod_n2, x_enc, xinv, count, &bad);
+  if (rc) return rc;
   rc = sc_modmul(ctx, k.mod_n2, y_enc, 2 * k.nw, xinv, 2 * k.nw, t, count); if (rc) return rc;                       // [[y]] [[x]]^-1
   rc = sc_paillier_encrypt_raw(ctx, k.mod_n2, k.cst_n, m1, k.nw + 1, xinv, count); if (rc) return rc;                // [[2^l + r]]
   if (!rho_z) return sc_modmul(ctx, k.mod_n2, t, 2 * k.nw, xinv, 2 * k.nw, z_out, count);
@@ -533,7 +534,8 @@ int sc_initiator_step4(sc_ctx* ctx, int dgk_key_id, int l, const uint32_t* d_enc
     joined = j;
   }
   int64_t bad = -1;
-  rc = sc_modinv(ctx, k.mod_n, joined, inv, items, &bad); if (rc) return rc;
+  rc = (flags & SC_STEP_DEFER_CHECKS) ? modinv_deferred(ctx, k.mod_n, joined, inv, items) : sc_modinv(ctx, k.mod_n, joined, inv, items, &bad);
+  if (rc) return rc;
   uint32_t* c_h = c_unblinded_out;
   if (!rhos) c_h = c_out;                                    // steps 4c-4h only
   else if (!c_h) { rc = tmp_words(ctx, TMP_S_G, items * row, &c_h); if (rc) return rc; }
@@ -601,7 +603,7 @@ int sc_keyholder_step4j_5(sc_ctx* ctx, int paillier_key_id, int dgk_key_id, int 
 }
 
 int sc_initiator_step67(sc_ctx* ctx, int paillier_key_id, const uint64_t* delta_a, const uint32_t* delta_b_enc, const uint32_t* zeta1_enc,
-                        const uint32_t* zeta2_enc, const uint64_t* rsmall, const uint32_t* rshift, uint32_t* out, uint64_t count) {
+                        const uint32_t* zeta2_enc, const uint64_t* rsmall, const uint32_t* rshift, int flags, uint32_t* out, uint64_t count) {
   if (ctx && count == 0) return SC_OK;
   const PaillierKey* kp = paillier_key(ctx, paillier_key_id);
   if (!kp || !delta_a || !delta_b_enc || !zeta1_enc || !zeta2_enc || !rsmall || !rshift || !out)
@@ -619,7 +621,8 @@ int sc_initiator_step67(sc_ctx* ctx, int paillier_key_id, const uint64_t* delta_
   rc = tmp_words(ctx, TMP_S_H, count * w2, &zeta); if (rc) return rc;
   rc = tmp_words(ctx, TMP_S_I, count, &flip); if (rc) return rc;
   int64_t bad = -1;
-  rc = sc_modinv(ctx, k.mod_n2, delta_b_enc, inv, count, &bad); if (rc) return rc;
+  rc = (flags & SC_STEP_DEFER_CHECKS) ? modinv_deferred(ctx, k.mod_n2, delta_b_enc, inv, count) : sc_modinv(ctx, k.mod_n2, delta_b_enc, inv, count, &bad);
+  if (rc) return rc;
   hipLaunchKernelGGL(k_select_rows, dim3(blocks_for(count * w2)), dim3(256), 0, ctx->stream, delta_a, inv, delta_b_enc, dfac, w2, count, flip, 1);
   hipLaunchKernelGGL(k_select_rows, dim3(blocks_for(count * w2)), dim3(256), 0, ctx->stream, rsmall, zeta1_enc, zeta2_enc, zeta, w2, count, (uint8_t*)nullptr, 0);
   HIPCHK(ctx, hipGetLastError());

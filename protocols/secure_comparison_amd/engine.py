@@ -612,7 +612,7 @@ class Engine:
                 raise ValueError(f"{name}: {t.numel()} items, expected {count}")
 
     def initiator_step1(self, key: PaillierKey, l: int, x_enc: torch.Tensor, y_enc: torch.Tensor, r: torch.Tensor,
-                        rho_z: torch.Tensor | None = None, ready: bool = False):
+                        rho_z: torch.Tensor | None = None, ready: bool = False, defer: bool = False):
         """(z_enc, alpha, alpha_tilde, r_small, r_shift): Initiator.step_1 / step_3 for a batch, [[z]] randomized with rho_z^N
         (`ready`: rho_z holds the finished randomizers rho_z^N mod N^2, [B][2nw], computed ahead of time)."""
         count = self._items(x_enc)
@@ -626,8 +626,8 @@ class Engine:
         alpha_t, rsmall = torch.empty_like(alpha), torch.empty_like(alpha)
         rshift = self.empty(count, nw)
         self._sync_stream()
-        rc = self.lib.sc_initiator_step1(self.ctx, key.id, int(l), self._ptr(x_enc), self._ptr(y_enc), self._ptr(r), self._ptr(rho_z), int(ready), self._ptr(z),
-                                         self._ptr(alpha), self._ptr(alpha_t), self._ptr(rsmall), self._ptr(rshift), count)
+        rc = self.lib.sc_initiator_step1(self.ctx, key.id, int(l), self._ptr(x_enc), self._ptr(y_enc), self._ptr(r), self._ptr(rho_z), int(ready) | (2 if defer else 0),
+                                         self._ptr(z), self._ptr(alpha), self._ptr(alpha_t), self._ptr(rsmall), self._ptr(rshift), count)
         self._check(rc)
         return z, alpha, alpha_t, rsmall, rshift
 
@@ -650,7 +650,7 @@ class Engine:
 
     def initiator_step4(self, key: DgkKey, l: int, d_enc: torch.Tensor, beta_enc: torch.Tensor, alpha: torch.Tensor, alpha_tilde: torch.Tensor,
                         rsmall: torch.Tensor, delta_a: torch.Tensor, rhos: torch.Tensor | None = None, permutation: torch.Tensor | None = None,
-                        r_rand: torch.Tensor | None = None, want_unblinded: bool = False, ready: bool = False):
+                        r_rand: torch.Tensor | None = None, want_unblinded: bool = False, ready: bool = False, defer: bool = False):
         """(c, c after step 4h or None): Initiator.step_4c .. 4i for a batch; see sc_initiator_step4 (`ready`: r_rand holds h^r)."""
         count = self._items(d_enc)
         nw = key.mod_n.nwords
@@ -668,8 +668,8 @@ class Engine:
         self._sync_stream()
         rc = self.lib.sc_initiator_step4(self.ctx, key.id, int(l), self._ptr(d_enc), self._ptr(beta_enc), self._ptr(alpha), self._ptr(alpha_tilde),
                                          self._ptr(rsmall), self._ptr(delta_a), self._ptr(rhos), 0 if rhos is None else rhos.shape[-1],
-                                         self._ptr(permutation), self._ptr(r_rand), 0 if r_rand is None else r_rand.shape[-1], int(ready),
-                                         self._ptr(mid), self._ptr(out), count)
+                                         self._ptr(permutation), self._ptr(r_rand), 0 if r_rand is None else r_rand.shape[-1],
+                                         int(ready) | (2 if defer else 0), self._ptr(mid), self._ptr(out), count)
         if rc == -3:
             raise NotInvertibleError(self.lib.sc_last_error(self.ctx).decode())
         self._check(rc)
@@ -712,7 +712,7 @@ class Engine:
         return delta_b, out
 
     def initiator_step67(self, key: PaillierKey, delta_a: torch.Tensor, delta_b_enc: torch.Tensor, zeta1_enc: torch.Tensor, zeta2_enc: torch.Tensor,
-                         rsmall: torch.Tensor, rshift: torch.Tensor) -> torch.Tensor:
+                         rsmall: torch.Tensor, rshift: torch.Tensor, defer: bool = False) -> torch.Tensor:
         count = self._items(delta_b_enc)
         nw = key.mod_n.nwords
         for name, t in (("delta_b_enc", delta_b_enc), ("zeta_1_enc", zeta1_enc), ("zeta_2_enc", zeta2_enc)):
@@ -722,11 +722,21 @@ class Engine:
         out = self.empty(count, 2 * nw)
         self._sync_stream()
         rc = self.lib.sc_initiator_step67(self.ctx, key.id, self._ptr(delta_a), self._ptr(delta_b_enc), self._ptr(zeta1_enc), self._ptr(zeta2_enc),
-                                          self._ptr(rsmall), self._ptr(rshift), self._ptr(out), count)
+                                          self._ptr(rsmall), self._ptr(rshift), 2 if defer else 0, self._ptr(out), count)
         if rc == -3:
             raise NotInvertibleError(self.lib.sc_last_error(self.ctx).decode())
         self._check(rc)
         return out
+
+    def check(self) -> None:
+        """Read the verdicts of every inversion queued with `defer=True` since the last check (sc_ctx_check: one synchronisation);
+        raises NotInvertibleError naming the element, as the undeferred calls do."""
+        self._sync_stream()
+        bad = C.c_int64(-1)
+        rc = self.lib.sc_ctx_check(self.ctx, C.byref(bad))
+        if rc == -3:
+            raise NotInvertibleError(self.lib.sc_last_error(self.ctx).decode(), int(bad.value))
+        self._check(rc)
 
     # ------------------------------------------------------------------ device-side CSPRNG (sc_rng_*)
     def rng_seed(self, key: bytes | None = None) -> None:

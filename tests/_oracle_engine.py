@@ -136,7 +136,10 @@ class OracleEngine:
         planes, count, nw = c.shape
         return self.modexp_shared_isone_any(key.mod_p, c.reshape(planes * count, nw), key.sk.v_p, count)
 
-    def initiator_step1(self, key, l, x_enc, y_enc, r, rho_z=None, ready=False):
+    def check(self):
+        pass
+
+    def initiator_step1(self, key, l, x_enc, y_enc, r, rho_z=None, ready=False, defer=False):
         n, n2 = key.mod_n.n, key.mod_n2.n
         m1, alpha, alpha_t, rsmall, rshift = self.plain_alice(r, n, l)
         z = self.modmul(key.mod_n2, self.modmul(key.mod_n2, y_enc, self.modinv(key.mod_n2, x_enc)), self.paillier_encrypt(key, m1))
@@ -184,7 +187,7 @@ class OracleEngine:
         return flat.reshape(lp1, count, nw)
 
     def initiator_step4(self, key, l, d_enc, beta_enc, alpha, alpha_tilde, rsmall, delta_a, rhos=None, permutation=None, r_rand=None,
-                        want_unblinded=False, ready=False):
+                        want_unblinded=False, ready=False, defer=False):
         count, nw = d_enc.shape
         inv = self.modinv(key.mod_n, torch.cat([d_enc.reshape(1, count, nw), beta_enc]).reshape((l + 1) * count, nw))
         c_h = self.dgk_step4(key.mod_n, key.sk.g, o.mod_inv(key.sk.g, key.mod_n.n), l, beta_enc, inv[count:].reshape(l, count, nw), d_enc,
@@ -202,7 +205,7 @@ class OracleEngine:
             enc = self.modmul(pkey.mod_n2, enc, rho3) if ready else self.paillier_randomize(pkey, enc, rho3)
         return delta_b, enc
 
-    def initiator_step67(self, key, delta_a, delta_b_enc, zeta1_enc, zeta2_enc, rsmall, rshift):
+    def initiator_step67(self, key, delta_a, delta_b_enc, zeta1_enc, zeta2_enc, rsmall, rshift, defer=False):
         # the LITERAL formulas of SC/initiator.py:529-531, 558-563 (two inversions): the library's one-inversion form must equal them
         n, n2 = key.mod_n.n, key.mod_n2.n
         out = []
