@@ -6,6 +6,7 @@ SC/keyholder.py:70-133), excluding key generation, table build, host RNG and tra
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 
 import torch
@@ -14,6 +15,13 @@ from ._views import cat_rows
 from .initiator import Initiator
 from .keyholder import KeyHolder
 from .schemes import DGK, Paillier
+
+
+# The batch driver CAN read the verdicts of a step's three inversions together at its end (defer_checks=True or
+# SC_AMD_DEFER_CHECKS=1: no host round trip inside the step, SC_STEP_DEFER_CHECKS / sc_ctx_check).  Measured on one box it changes
+# nothing at B = 65536 (174.2 / 173.2 k against 174.4 / 173.9 k with two shards, 166.8 against 166.5 k on one stream) and costs 2 % at
+# B = 4096 with the second context (99.2 against 101.1 k), so the default stays one round trip per inversion.
+_DEFER = os.environ.get("SC_AMD_DEFER_CHECKS", "0") == "1"
 
 
 @dataclass
@@ -122,7 +130,7 @@ class _AheadOfTime:
 
 def secure_comparison_batch(x_enc: torch.Tensor, y_enc: torch.Tensor, l: int, alice_paillier: Paillier, alice_dgk: DGK,
                             bob_paillier: Paillier, bob_dgk: DGK, draws: BatchDraws, randomize: bool | str = True,
-                            trace: BatchTrace | None = None, side: "PartySet | None" = None) -> torch.Tensor:
+                            trace: BatchTrace | None = None, side: "PartySet | None" = None, defer_checks: bool | None = None) -> torch.Tensor:
     """[[x <= y]] for B comparisons.  x_enc, y_enc: [B][2nw] Paillier ciphertexts under Bob's key.
     randomize: True = every `.randomize()` of the interactive protocol, computed from the injected randomizer inputs in `draws`;
     "pool" = the same randomizations with pre-generated randomizers from the schemes' device pools (boot_pools), i.e. the
@@ -133,20 +141,22 @@ def secure_comparison_batch(x_enc: torch.Tensor, y_enc: torch.Tensor, l: int, al
     call, so they are part of the step; identical results."""
     if randomize == "pool":
         return _secure_comparison_batch_pooled(x_enc, y_enc, l, alice_paillier, alice_dgk, bob_paillier, bob_dgk, draws)
+    defer = _DEFER if defer_checks is None else bool(defer_checks)
     if side is not None and randomize:
         ahead = _AheadOfTime(side, draws, l)
         count = x_enc.shape[0]
-        z_enc, a_plain = Initiator.step_1_batch(x_enc, y_enc, l, alice_paillier, draws.r, None, defer_checks=True)
+        z_enc, a_plain = Initiator.step_1_batch(x_enc, y_enc, l, alice_paillier, draws.r, None, defer_checks=defer)
         z_enc = alice_paillier.add_batch(z_enc, ahead.take("rz"))
         b_plain, d_enc, beta_enc = KeyHolder.step_2_4b_batch(z_enc, l, bob_paillier, bob_dgk,
                                                              ahead.take("hr_bob").reshape(l + 1, count, -1), randomizers_ready=True)
         c_sent, c_h = Initiator.step_4_batch(d_enc, beta_enc, a_plain, draws.delta_a, alice_dgk, draws.rhos, draws.permutation,
                                              ahead.take("hr_alice").reshape(l + 1, count, -1), want_unblinded=trace is not None,
-                                             randomizers_ready=True, defer_checks=True)
+                                             randomizers_ready=True, defer_checks=defer)
         delta_b, zeta_1_enc, zeta_2_enc, delta_b_enc = KeyHolder.step_4j_5_batch(c_sent, b_plain, bob_paillier, bob_dgk, ahead.take("r3"),
                                                                                  randomizers_ready=True)
-        result = Initiator.step_6_7_batch(draws.delta_a, delta_b_enc, zeta_1_enc, zeta_2_enc, a_plain, l, alice_paillier, defer_checks=True)
-        _check_engines(alice_paillier, alice_dgk)
+        result = Initiator.step_6_7_batch(draws.delta_a, delta_b_enc, zeta_1_enc, zeta_2_enc, a_plain, l, alice_paillier, defer_checks=defer)
+        if defer:
+            _check_engines(alice_paillier, alice_dgk)
         if trace is not None:
             trace.z_enc, trace.z, trace.d_enc, trace.beta_enc = z_enc, b_plain.z, d_enc, beta_enc
             trace.c_step4h, trace.c_sent, trace.delta_b = c_h, c_sent, delta_b
@@ -154,20 +164,21 @@ def secure_comparison_batch(x_enc: torch.Tensor, y_enc: torch.Tensor, l: int, al
         return result
     # five library calls per batch (include/sc_amd.h, scheme-level entry points)
     # Alice: steps 1, 3 (+ the randomization of [[z]])
-    # (no host round trip inside the step: the three inversions' verdicts are read together at the end, batch-driver only --
-    # a party of the interactive protocol checks before it sends)
-    z_enc, a_plain = Initiator.step_1_batch(x_enc, y_enc, l, alice_paillier, draws.r, draws.rho_z if randomize else None, defer_checks=True)
+    # (defer: no host round trip inside the step -- the three inversions' verdicts are read together at the end; batch driver
+    # only: a party of the interactive protocol checks before it sends)
+    z_enc, a_plain = Initiator.step_1_batch(x_enc, y_enc, l, alice_paillier, draws.r, draws.rho_z if randomize else None, defer_checks=defer)
     # Bob: steps 2, 4a, 4b (+ l + 1 randomizations)
     b_plain, d_enc, beta_enc = KeyHolder.step_2_4b_batch(z_enc, l, bob_paillier, bob_dgk, draws.r_bob_dgk if randomize else None)
     # Alice: steps 4c-4i (+ l + 1 randomizations, shuffle)
     c_sent, c_h = Initiator.step_4_batch(d_enc, beta_enc, a_plain, draws.delta_a, alice_dgk, draws.rhos, draws.permutation,
-                                         draws.r_alice_dgk if randomize else None, want_unblinded=trace is not None, defer_checks=True)
+                                         draws.r_alice_dgk if randomize else None, want_unblinded=trace is not None, defer_checks=defer)
     # Bob: steps 4j, 5 (+ 3 randomizations)
     rho3 = cat_rows([draws.rho_zeta_1, draws.rho_zeta_2, draws.rho_delta_b]) if randomize else None   # three blocks of one array: a view
     delta_b, zeta_1_enc, zeta_2_enc, delta_b_enc = KeyHolder.step_4j_5_batch(c_sent, b_plain, bob_paillier, bob_dgk, rho3)
     # Alice: steps 6, 7
-    result = Initiator.step_6_7_batch(draws.delta_a, delta_b_enc, zeta_1_enc, zeta_2_enc, a_plain, l, alice_paillier, defer_checks=True)
-    _check_engines(alice_paillier, alice_dgk)
+    result = Initiator.step_6_7_batch(draws.delta_a, delta_b_enc, zeta_1_enc, zeta_2_enc, a_plain, l, alice_paillier, defer_checks=defer)
+    if defer:
+        _check_engines(alice_paillier, alice_dgk)
     if trace is not None:
         trace.z_enc, trace.z, trace.d_enc, trace.beta_enc = z_enc, b_plain.z, d_enc, beta_enc
         trace.c_step4h, trace.c_sent, trace.delta_b = c_h, c_sent, delta_b

@@ -398,14 +398,16 @@ def test_deferred_inversion_verdicts_still_name_the_element(engine, keys):
     l, B = 16, 5000            # above the inversion tree's top: several levels
     alice_p, alice_d, bob_p, bob_d = _schemes(engine, sk, dgk, 400)
     x, y, x_enc, y_enc, draws = bench.synth_inputs(engine, l, alice_p, bob_p, bob_d, B, 400, seed=4, shuffle=True)
-    good = secure_comparison_batch(x_enc, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws)
+    good = secure_comparison_batch(x_enc, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws, defer_checks=True)
+    assert torch.equal(good, secure_comparison_batch(x_enc, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws, defer_checks=False))
     poisoned = x_enc.clone()
     poisoned[3777] = engine.upload([sk.p * 12345], x_enc.shape[-1])[0]          # gcd(x, N^2) = p
-    with pytest.raises(NotInvertibleError) as ei:
-        secure_comparison_batch(poisoned, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws)
-    assert ei.value.index == 3777
+    for defer in (True, False):
+        with pytest.raises(NotInvertibleError) as ei:
+            secure_comparison_batch(poisoned, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws, defer_checks=defer)
+        assert ei.value.index == 3777
     engine.check()                                                              # nothing pending any more
-    again = secure_comparison_batch(x_enc, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws)
+    again = secure_comparison_batch(x_enc, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws, defer_checks=True)
     assert torch.equal(again, good)
     dec = bob_p.decrypt_raw_batch(again)
     assert bool((dec[:, 0] == (x <= y).to(torch.int32)).all().item())
