@@ -48,6 +48,9 @@ void sc_ctx_destroy(sc_ctx* ctx);
 int sc_ctx_set_stream(sc_ctx* ctx, void* hip_stream);   /* hipStream_t; NULL = default stream */
 int sc_ctx_synchronize(sc_ctx* ctx);
 const char* sc_last_error(sc_ctx* ctx);
+/* The element named by the most recent SC_ERR_NOT_INVERTIBLE of this context (-1 before the first): the step-level entry points
+ * have no bad_index parameter of their own. */
+int64_t sc_last_bad_index(sc_ctx* ctx);
 /* Bumped whenever an entry point is added or changes meaning; the binding checks it (round 1: 1, round 2 shipped 1 by mistake, round 3: 3). */
 #define SC_ABI_VERSION 3
 int sc_abi_version(void);

@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("SC_AMD_LIB", os.path.join(HERE, "libsc_amd.so"))  # o
 
 # every symbol include/sc_amd.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "sc_ctx_create", "sc_ctx_destroy", "sc_ctx_set_stream", "sc_ctx_synchronize", "sc_last_error", "sc_abi_version",
+    "sc_ctx_create", "sc_ctx_destroy", "sc_ctx_set_stream", "sc_ctx_synchronize", "sc_last_error", "sc_last_bad_index", "sc_abi_version",
     "sc_malloc", "sc_free", "sc_memcpy_h2d", "sc_memcpy_d2h",
     "sc_mod_create", "sc_mod_words", "sc_exp_create", "sc_const_create", "sc_fbt_create", "sc_fbt_import", "sc_fbt_bytes",
     "sc_modmul", "sc_modmul_const", "sc_modmul_const_sel", "sc_modexp_shared", "sc_modexp_shared_sq", "sc_mod_supports_sq", "sc_modexp_shared_isone", "sc_modexp_shared_isone_any", "sc_fixedbase_pow", "sc_modexp_var", "sc_modexp_var_scatter",
@@ -51,6 +51,7 @@ def load() -> C.CDLL:
         "sc_ctx_set_stream": (i32, [vp, vp]),
         "sc_ctx_synchronize": (i32, [vp]),
         "sc_last_error": (C.c_char_p, [vp]),
+        "sc_last_bad_index": (C.c_int64, [vp]),
         "sc_abi_version": (i32, []),
         "sc_malloc": (i32, [vp, C.c_size_t, C.POINTER(vp)]),
         "sc_free": (i32, [vp, vp]),

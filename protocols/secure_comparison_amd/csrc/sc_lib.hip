@@ -166,6 +166,7 @@ struct sc_ctx {
   hipEvent_t switch_event = nullptr;   // orders the work of the previous stream before the next one (sc_ctx_set_stream)
   int num_cu = 256;
   std::string err;
+  int64_t last_bad_index = -1;                              // the element named by the last SC_ERR_NOT_INVERTIBLE (sc_last_bad_index)
   std::vector<Mod> mods;
   std::vector<Exp> exps;
   std::vector<Const> consts;
@@ -672,6 +673,7 @@ int sc_ctx_set_stream(sc_ctx* ctx, void* hip_stream) {
 }
 int sc_ctx_synchronize(sc_ctx* ctx) { if (!ctx) return SC_ERR_ARG; HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); return SC_OK; }
 const char* sc_last_error(sc_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+int64_t sc_last_bad_index(sc_ctx* ctx) { return ctx ? ctx->last_bad_index : -1; }
 
 int sc_malloc(sc_ctx* ctx, size_t bytes, void** out_dptr) {
   if (!ctx || !out_dptr) return SC_ERR_ARG;
@@ -1264,6 +1266,7 @@ int sc_modinv(sc_ctx* ctx, int mod, const uint32_t* x, uint32_t* out, uint64_t c
     bad = member;
   }
   if (bad_index) *bad_index = bad;
+  ctx->last_bad_index = bad;
   return fail(ctx, SC_ERR_NOT_INVERTIBLE, "element %lld is not invertible", (long long)bad);
 }
 

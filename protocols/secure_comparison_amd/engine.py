@@ -104,7 +104,7 @@ class Engine:
         if rc == -1:
             raise ValueError(msg)
         if rc == -3:
-            raise NotInvertibleError(msg)
+            raise NotInvertibleError(msg, int(self.lib.sc_last_bad_index(self.ctx)))
         raise ScError(f"{msg} (status {rc})")
 
     def _sync_stream(self) -> None:
@@ -670,8 +670,6 @@ class Engine:
                                          self._ptr(rsmall), self._ptr(delta_a), self._ptr(rhos), 0 if rhos is None else rhos.shape[-1],
                                          self._ptr(permutation), self._ptr(r_rand), 0 if r_rand is None else r_rand.shape[-1],
                                          int(ready) | (2 if defer else 0), self._ptr(mid), self._ptr(out), count)
-        if rc == -3:
-            raise NotInvertibleError(self.lib.sc_last_error(self.ctx).decode())
         self._check(rc)
         return out, mid
 
@@ -723,8 +721,6 @@ class Engine:
         self._sync_stream()
         rc = self.lib.sc_initiator_step67(self.ctx, key.id, self._ptr(delta_a), self._ptr(delta_b_enc), self._ptr(zeta1_enc), self._ptr(zeta2_enc),
                                           self._ptr(rsmall), self._ptr(rshift), 2 if defer else 0, self._ptr(out), count)
-        if rc == -3:
-            raise NotInvertibleError(self.lib.sc_last_error(self.ctx).decode())
         self._check(rc)
         return out
 
