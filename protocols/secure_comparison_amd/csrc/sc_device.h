@@ -63,8 +63,12 @@ __device__ __forceinline__ uint32_t row_from_below(uint32_t v) {
 // ---------------------------------------------------------------------------------------------
 // Per-thread view of the group it belongs to.
 // ---------------------------------------------------------------------------------------------
-template <int G_, int L_, int W_ = W_DEFAULT>
+// NEG1: the modulus satisfies n = -1 (mod 2^W), i.e. -n^-1 = 1: the Montgomery quotient digit is the low limb of the running sum
+// itself and the v_mul_lo_u32 of every limb step disappears from the dependent chain.  An arbitrary odd n gets there through the
+// multiple M = (-n^-1 mod 2^W) n, whose residues reduce to residues modulo n (sc_lib.hip::neg1_twin).
+template <int G_, int L_, int W_ = W_DEFAULT, bool NEG1_ = false>
 struct Grp {
+  static constexpr bool NEG1 = NEG1_;
   static constexpr int G = G_, L = L_, S = G_ * L_, NG = 64 / G_;
   static constexpr int W = W_;                          // bits per limb: 2L products of 2W bits must fit 64 bits
   static constexpr uint32_t LMASK = (1u << W_) - 1;
@@ -158,7 +162,7 @@ struct Grp {
 #pragma unroll
           for (int c = l + 1; c < L; c++) T[(l + c) % L] += (uint64_t)ai2 * b[c];
         }
-        const uint32_t q = bcast0<G>((uint32_t)T[l] * n0inv) & lmask_v;   // broadcast first: the mask folds into the DPP op
+        const uint32_t q = bcast0<G>(NEG1 ? (uint32_t)T[l] : (uint32_t)T[l] * n0inv) & lmask_v;   // broadcast first: the mask folds into the DPP op
         if constexpr (COLLECT) quot[l] = (j == k) ? q : quot[l];
 #pragma unroll
         for (int c = 0; c < L; c++) T[(l + c) % L] += (uint64_t)q * n[c];
@@ -267,7 +271,7 @@ struct Grp {
         for (int c = 0; c < L; c++) T[(l + c) % L] += (uint64_t)a1 * b1[c];
 #pragma unroll
         for (int c = 0; c < L; c++) T[(l + c) % L] += (uint64_t)a2 * b2[c];
-        const uint32_t q = bcast0<G>((uint32_t)T[l] * n0inv) & lmask_v;
+        const uint32_t q = bcast0<G>(NEG1 ? (uint32_t)T[l] : (uint32_t)T[l] * n0inv) & lmask_v;
 #pragma unroll
         for (int c = 0; c < L; c++) T[(l + c) % L] += (uint64_t)q * n[c];
         const uint64_t t0 = T[l];

@@ -271,9 +271,9 @@ __global__ void __launch_bounds__(64, (G == 1 && L == 37) ? 2 : (L == 27 ? SC_L2
 // The pair interpreter: exponentiation modulo n^2 carried out with Montgomery products modulo n only (sc_device.h,
 // "pair arithmetic").  Same launch geometry and argument block as k_vm; compiled for the L = 18 configurations.
 // ---------------------------------------------------------------------------------------------
-template <int G, int L, int WB>
+template <int G, int L, int WB, bool NEG1 = false>
 __global__ void __launch_bounds__(64, ((G == 16 && L > 9) ? 1 : SC_PVM_WAVES)) k_pvm(const VmArgs args) {
-  using GT = Grp<G, L, WB>;
+  using GT = Grp<G, L, WB, NEG1>;
   constexpr int S = GT::S, NG = GT::NG, SP = GT::SP, WP = GT::WP;
   __shared__ uint32_t s_a[NG * SP];            // first LDS-side operand  (x0, or y0)
   __shared__ uint32_t s_a2[G == 1 ? 1 : NG * SP];  // 2 * x0 (squarings) or y1 (products); also the word scratch of PV_LOADU

@@ -69,6 +69,7 @@ Big big_shl_mod(const Big& x, const Big& n, int k) {
   v.resize(n.size());
   return v;
 }
+Big big_trimmed_words(Big a) { while (a.size() > 1 && a.back() == 0) a.pop_back(); return a; }
 Big big_mul(const Big& a, const Big& b) {  // schoolbook product (set-up time only)
   Big r(a.size() + b.size(), 0);
   for (size_t i = 0; i < a.size(); i++) {
@@ -188,6 +189,7 @@ struct sc_ctx {
   int comm_rank = 0, comm_nranks = 0;
   std::map<int, int> onelane_twins;                         // mod -> context of the same modulus in the one-lane configuration
   std::map<int, int> pair_twins;                            // mod -> context of the same modulus in a pair-capable configuration
+  std::map<int, int> neg1_twins;                            // (4,18) mod n -> context of the multiple M = c n = -1 (mod 2^29)
   std::map<int, int> latency_pair_twins;                    // mod -> context of the same modulus in the (16,5) / (8,5) small-batch pair configuration
   std::map<int, uint32_t*> pair_consts;                     // mod -> 4 limb arrays: pair(R^2), pair(B R) for the pair arithmetic
   RngKey rng_key;                                           // ChaCha20 key of the context's generator (sc_rng_seed)
@@ -492,15 +494,15 @@ int run_vm(sc_ctx* ctx, int mod, const Prog& p, const VmExt* exts, int next, uin
   return rc;
 }
 
-template <int G, int L, int WB = 29>
+template <int G, int L, int WB = 29, bool NEG1 = false>
 int launch_pvm_cfg(sc_ctx* ctx, const VmArgs& a) {
   constexpr int NG = 64 / G;
-  const int key = 1000 + 100 * L + G;
+  const int key = 1000 + 100 * L + G + (NEG1 ? 100000 : 0);
   auto it = ctx->occ_cache.find(key);
   int occ;
   if (it == ctx->occ_cache.end()) {
     int nb = 0;
-    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_pvm<G, L, WB>, 64, 0));
+    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_pvm<G, L, WB, NEG1>, 64, 0));
     occ = std::max(1, std::min(nb, 16));
     ctx->occ_cache[key] = occ;
   } else {
@@ -511,7 +513,7 @@ int launch_pvm_cfg(sc_ctx* ctx, const VmArgs& a) {
   VmArgs args = a;
   int rc = ensure_scratch(ctx, (size_t)grid * NG * a.nscratch * (G * L) * 4, &args.scratch);
   if (rc) return rc;
-  hipLaunchKernelGGL((k_pvm<G, L, WB>), dim3(grid), dim3(64), 0, ctx->stream, args);
+  hipLaunchKernelGGL((k_pvm<G, L, WB, NEG1>), dim3(grid), dim3(64), 0, ctx->stream, args);
   HIPCHK(ctx, hipGetLastError());
   return SC_OK;
 }
@@ -535,7 +537,7 @@ int run_pvm(sc_ctx* ctx, int mod, const Prog& p, const VmExt* exts, int next, ui
   if (m.L == 18) switch (m.G) {
     case 1: return launch_pvm_cfg<1, 18>(ctx, a);
     case 2: return launch_pvm_cfg<2, 18>(ctx, a);
-    case 4: return launch_pvm_cfg<4, 18>(ctx, a);
+    case 4: return m.n0inv == 1 ? launch_pvm_cfg<4, 18, 29, true>(ctx, a) : launch_pvm_cfg<4, 18>(ctx, a);   // n = -1 (mod 2^29): no quotient multiply
     case 8: return launch_pvm_cfg<8, 18>(ctx, a);
     case 16: return launch_pvm_cfg<16, 18>(ctx, a);
   }
@@ -1515,6 +1517,30 @@ static int latency_pair_twin(sc_ctx* ctx, int mod, uint64_t count) {
   return twin;
 }
 
+// The twin of a (4,18) modulus n whose own modulus is the multiple M = c n, c = -n^-1 mod 2^29, so that M = -1 (mod 2^29): in its
+// context the Montgomery quotient digit needs no multiplication (Grp::NEG1).  M has at most 29 more bits than n; the (4,18)
+// configuration holds 2088 bits, so 2048-bit moduli fit (R / M >= 2^11).  Residues modulo M (and pairs modulo M^2) reduce to
+// residues modulo n (n^2): the caller finishes in a context of the original modulus.  -1: no such twin (other configurations,
+// moduli too long, or n already = -1).
+static int neg1_twin(sc_ctx* ctx, int mod) {
+  auto it = ctx->neg1_twins.find(mod);
+  if (it != ctx->neg1_twins.end()) return it->second;
+  int twin = -1;
+  {
+    const Mod m = ctx->mods[mod];
+    static const bool enabled = []{ const char* e = getenv("SC_NEG1"); return !(e && e[0] == '0'); }();      // A/B switch (dev): SC_NEG1=0
+    if (enabled && m.G == 4 && m.L == 18 && m.W == 29 && m.n0inv != 1 && m.nbits + 29 + 8 <= m.W * m.S) {
+      Big c(1, m.n0inv);
+      Big M = big_trimmed_words(big_mul(m.n, c));
+      const Config same = {m.G, m.L, m.W, false};
+      if (create_mod(ctx, M.data(), (int)M.size(), false, &twin, &same) != SC_OK) twin = -1;
+      if (twin >= 0 && ctx->mods[twin].n0inv != 1) twin = -1;     // (cannot happen: M = -1 mod 2^29 by construction)
+    }
+  }
+  ctx->neg1_twins[mod] = twin;
+  return twin;
+}
+
 // The one-lane twin of `mod` when this batch should run on it, else `mod` itself.  Automatic policy: the modulus fits the
 // one-lane configuration and the batch is at least one and a half rounds of the chip's resident one-lane waves (2 per SIMD, 64
 // numbers each: 196608 numbers on 256 CUs).  Measured on the MI355X (1024-bit modulus, 1024-bit exponent): 196608 numbers 19.8 ->
@@ -1573,15 +1599,20 @@ int sc_modexp_shared_sq(sc_ctx* ctx, int mod_m, int mod_m2, int exp, const uint3
     mod_m = lat >= 0 ? lat : pair_twin(ctx, mod_m);
   }
   if (mod_m < 0) return fail(ctx, SC_ERR_UNSUPPORTED, "sc_modexp_shared_sq: no pair configuration fits this modulus");
-  const Mod& m = ctx->mods[mod_m];
-  const Mod& m2 = ctx->mods[mod_m2];
   {
-    Big sq = big_mul(m.n, m.n);
+    const Mod& m0 = ctx->mods[mod_m];
+    const Mod& m2 = ctx->mods[mod_m2];
+    Big sq = big_mul(m0.n, m0.n);
     sq.resize(std::max(sq.size(), m2.n.size()), 0);
     Big other = m2.n; other.resize(sq.size(), 0);
     if (big_cmp(sq, other) != 0) return fail(ctx, SC_ERR_ARG, "sc_modexp_shared_sq: mod_m2 is not the square of mod_m");
+    if (x_words > 4 * m0.nwords) return fail(ctx, SC_ERR_ARG, "sc_modexp_shared_sq: operand wider than 4 chunks");
   }
-  if (x_words > 4 * m.nwords) return fail(ctx, SC_ERR_ARG, "sc_modexp_shared_sq: operand wider than 4 chunks");
+  // chip-filling batches of a (4,18) modulus: the pair launch runs modulo the multiple M = c m = -1 (mod 2^29), which needs no
+  // quotient multiply; the assembly launch below reduces w0 + w1 M modulo m^2 (m | M)
+  if (!use_latency_config(ctx, ctx->mods[mod_m], count)) { const int t = neg1_twin(ctx, mod_m); if (t >= 0) mod_m = t; }
+  const Mod& m = ctx->mods[mod_m];
+  const Mod& m2 = ctx->mods[mod_m2];
   const Exp& ex = ctx->exps[exp];
   const int wm = m.nwords + 1;                                           // words of the raw pair halves (< 2m + 1)
   uint32_t* d_w;
