@@ -542,8 +542,8 @@ int run_pvm(sc_ctx* ctx, int mod, const Prog& p, const VmExt* exts, int next, ui
     case 16: return launch_pvm_cfg<16, 18>(ctx, a);
   }
   if (m.L == 14) switch (m.G) {
-    case 4: return launch_pvm_cfg<4, 14>(ctx, a);
-    case 8: return launch_pvm_cfg<8, 14>(ctx, a);
+    case 4: return m.n0inv == 1 ? launch_pvm_cfg<4, 14, 29, true>(ctx, a) : launch_pvm_cfg<4, 14>(ctx, a);
+    case 8: return m.n0inv == 1 ? launch_pvm_cfg<8, 14, 29, true>(ctx, a) : launch_pvm_cfg<8, 14>(ctx, a);
   }
   if (m.L == 5) switch (m.G) {
     case 8: return launch_pvm_cfg<8, 5>(ctx, a);
@@ -1517,9 +1517,10 @@ static int latency_pair_twin(sc_ctx* ctx, int mod, uint64_t count) {
   return twin;
 }
 
-// The twin of a (4,18) modulus n whose own modulus is the multiple M = c n, c = -n^-1 mod 2^29, so that M = -1 (mod 2^29): in its
-// context the Montgomery quotient digit needs no multiplication (Grp::NEG1).  M has at most 29 more bits than n; the (4,18)
-// configuration holds 2088 bits, so 2048-bit moduli fit (R / M >= 2^11).  Residues modulo M (and pairs modulo M^2) reduce to
+// The twin of a (4,18) / (4,14) / (8,14) modulus n whose own modulus is the multiple M = c n, c = -n^-1 mod 2^29, so that M = -1
+// (mod 2^29): in its context the Montgomery quotient digit needs no multiplication (Grp::NEG1).  M has at most 29 more bits than n;
+// the (4,18) configuration holds 2088 bits, so 2048-bit moduli fit (R / M >= 2^11), and the L = 14 pair twins of 1536 / 3072-bit
+// moduli (1624 / 3248 bits) have the room as well.  Residues modulo M (and pairs modulo M^2) reduce to
 // residues modulo n (n^2): the caller finishes in a context of the original modulus.  -1: no such twin (other configurations,
 // moduli too long, or n already = -1).
 static int neg1_twin(sc_ctx* ctx, int mod) {
@@ -1529,7 +1530,8 @@ static int neg1_twin(sc_ctx* ctx, int mod) {
   {
     const Mod m = ctx->mods[mod];
     static const bool enabled = []{ const char* e = getenv("SC_NEG1"); return !(e && e[0] == '0'); }();      // A/B switch (dev): SC_NEG1=0
-    if (enabled && m.G == 4 && m.L == 18 && m.W == 29 && m.n0inv != 1 && m.nbits + 29 + 8 <= m.W * m.S) {
+    const bool has_kernel = m.W == 29 && ((m.L == 18 && m.G == 4) || (m.L == 14 && (m.G == 4 || m.G == 8)));   // k_pvm<.., true> instances
+    if (enabled && has_kernel && m.n0inv != 1 && m.nbits + 29 + 8 <= m.W * m.S) {
       Big c(1, m.n0inv);
       Big M = big_trimmed_words(big_mul(m.n, c));
       const Config same = {m.G, m.L, m.W, false};
@@ -1608,8 +1610,8 @@ int sc_modexp_shared_sq(sc_ctx* ctx, int mod_m, int mod_m2, int exp, const uint3
     if (big_cmp(sq, other) != 0) return fail(ctx, SC_ERR_ARG, "sc_modexp_shared_sq: mod_m2 is not the square of mod_m");
     if (x_words > 4 * m0.nwords) return fail(ctx, SC_ERR_ARG, "sc_modexp_shared_sq: operand wider than 4 chunks");
   }
-  // chip-filling batches of a (4,18) modulus: the pair launch runs modulo the multiple M = c m = -1 (mod 2^29), which needs no
-  // quotient multiply; the assembly launch below reduces w0 + w1 M modulo m^2 (m | M)
+  // chip-filling batches of a (4,18) / (4,14) / (8,14) modulus: the pair launch runs modulo the multiple M = c m = -1 (mod 2^29),
+  // which needs no quotient multiply; the assembly launch below reduces w0 + w1 M modulo m^2 (m | M)
   if (!use_latency_config(ctx, ctx->mods[mod_m], count)) { const int t = neg1_twin(ctx, mod_m); if (t >= 0) mod_m = t; }
   const Mod& m = ctx->mods[mod_m];
   const Mod& m2 = ctx->mods[mod_m2];
