@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "sc_lib.hip")
 OUT = os.path.join(HERE, "libsc_amd.so")
-DEPS = [os.path.join(HERE, "csrc", f) for f in ("sc_lib.hip", "sc_kernels.h", "sc_device.h", "sc_vm.h", "sc_xgcd.h")] + [
+DEPS = sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith((".hip", ".h"))) + [
     os.path.join(HERE, "..", "..", "include", "sc_amd.h")
 ]
 
