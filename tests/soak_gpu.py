@@ -1,4 +1,4 @@
-"""Soak run of the headline configuration (not collected by pytest: `python tests/soak_gpu.py <seconds> <seed> [B]`).
+"""Soak run of the headline configuration (not collected by pytest: `python tests/soak_gpu.py <seconds> <seed> [B [pbits dgk_key_name l]]`).
 
 BASELINE configs[2] as bench.py runs it -- B = 65536, l = 32, 2048/2048-bit keys, two concurrent shards with shared window-16
 tables, every randomization and the step-4i shuffle -- over and over with FRESH inputs and draws per batch (another seed each
@@ -34,8 +34,11 @@ def main() -> int:
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     B = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
     keys = json.load(open(os.path.join(GOLDEN, "keys.json")))
-    sk, dgk = oracle_paillier(keys, 2048), oracle_dgk(keys, "dgk_2048_l32")
-    l, rbits, window = 32, 400, bench.DEFAULT_FB_WINDOW
+    pbits = int(sys.argv[4]) if len(sys.argv) > 4 else 2048                  # other BASELINE shapes: e.g. 32768 3072 dgk_3072_l64 64
+    dname = sys.argv[5] if len(sys.argv) > 5 else "dgk_2048_l32"
+    l = int(sys.argv[6]) if len(sys.argv) > 6 else 32
+    sk, dgk = oracle_paillier(keys, pbits), oracle_dgk(keys, dname)
+    rbits, window = 400, bench.DEFAULT_FB_WINDOW
     engines = [Engine(), Engine()]
     sets = []
     for i, e in enumerate(engines):
@@ -77,7 +80,7 @@ def main() -> int:
         runner.close()
         for e in engines:
             e.close()
-    print(f"soak finished: {batches} batches of {B} = {batches * B} comparisons decrypt to [x <= y]; {rows_checked} sampled rows equal the oracle bit for bit; seed {seed0}")
+    print(f"soak finished ({pbits}-bit Paillier, {dname}, l = {l}): {batches} batches of {B} = {batches * B} comparisons decrypt to [x <= y]; {rows_checked} sampled rows equal the oracle bit for bit; seed {seed0}")
     return 0
 
 
