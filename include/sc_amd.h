@@ -177,8 +177,8 @@ int sc_paillier_l_mul(sc_ctx* ctx, int mod, int cst_k, const uint32_t* x_dptr, i
                       uint64_t count);
 
 /* out[i] = the x in [0, m_p m_q) with x = a_p[i] (mod m_p), x = a_q[i] (mod m_q):  a_q + m_q ((a_p - a_q) m_q^-1 mod m_p).
- * Used by the key holder to recombine the CRT halves of decrypt (m_p = p, m_q = q) and of rho^N (m_p = p^2, m_q = q^2);
- * identical integers to the reference's single-modulus pow_mod.  Constants: cst_k = m_q^-1 mod m_p and cst_negk =
+ * Used by the key holder to recombine the CRT halves of decrypt (m_p = p, m_q = q; SC/keyholder.py:195) and of rho^N (m_p = p^2,
+ * m_q = q^2; SC/keyholder.py:126-128); identical integers to the reference's single-modulus pow_mod.  Constants: cst_k = m_q^-1 mod m_p and cst_negk =
  * m_p - cst_k registered for mod_p, cst_mq = m_q registered for mod_full (= m_p m_q). */
 int sc_crt_combine(sc_ctx* ctx, int mod_p, int mod_full, int cst_k, int cst_negk, int cst_mq, const uint32_t* a_p_dptr,
                    int a_p_words, const uint32_t* a_q_dptr, int a_q_words, uint32_t* out_dptr, uint64_t count);
@@ -229,6 +229,10 @@ int sc_dgk_step4(sc_ctx* ctx, int mod, int cst_g, int cst_ginv, int l, const uin
  * parties in one process; a party that is about to SEND a step's output checks first. */
 #define SC_STEP_DEFER_CHECKS 2
 int sc_ctx_check(sc_ctx* ctx, int64_t* bad_index /* nullable */);
+/* Paillier key: the public modulus N and optionally the secret primes p, q (key holder) -- what `Paillier.from_security_parameter`
+ * produces at SC/keyholder.py:155-158 and what the initiator receives as the public scheme (SC/initiator.py:177-203).  Every derived
+ * modulus (N, N^2, p, q, p^2, q^2), exponent (N, lambda, p - 1, q - 1, q mod p - 1, ..), CRT constant and the pair contexts are
+ * registered once; flags: SC_KEY_NO_CRT / SC_KEY_NO_PAIRS keep the literal single-modulus forms (tests, A/B). */
 int sc_paillier_key_create(sc_ctx* ctx, const uint32_t* n_hptr, int nwords, const uint32_t* p_hptr /* nullable */,
                            const uint32_t* q_hptr /* nullable */, int pwords, int flags, int* out_key);
 /* the primitive handles behind a key (for callers that mix scheme-level and primitive calls) */
@@ -242,7 +246,7 @@ int sc_paillier_randomize(sc_ctx* ctx, int key, const uint32_t* c_dptr /* nullab
                           uint64_t count);
 /* Paillier.decrypt(ct, apply_encoding=False): out[i] = L(c[i]^lambda mod N^2) mu mod N, [count][nwords] (SC/keyholder.py:195). */
 int sc_paillier_decrypt(sc_ctx* ctx, int key, const uint32_t* c_dptr, uint32_t* out_dptr, uint64_t count);
-/* DGK key: public (n, g, h, u, t) and optionally secret (p, q, v_p, v_q); randomizer_bits = width of the exponent r of h^r ([ext]
+/* DGK key (`DGK.from_security_parameter`, SC/keyholder.py:161-166): public (n, g, h, u, t) and optionally secret (p, q, v_p, v_q); randomizer_bits = width of the exponent r of h^r ([ext]
  * ~2.5 t), window = fixed-base window of the tables for h (2^window rows per window).  table_src_ctx / table_src_key (nullable /
  * ignored): another context of the same GPU whose key of the same modulus, h, window and width already built the tables -- they
  * are shared read-only instead of built again (concurrent shard contexts; see sc_fbt_import). */
