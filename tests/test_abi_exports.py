@@ -40,3 +40,27 @@ def test_no_gpu_means_loud_failure():
 
     with pytest.raises(ScError):
         Engine()
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/sc_amd.h is the boundary a C / cgo / JNI host binds: it must compile as strict C99 (no C++-isms outside the
+    extern "C" guard) and a C program must link against libsc_amd.so and reach an entry point without Python or a GPU."""
+    import shutil
+    import subprocess
+
+    from protocols.secure_comparison_amd import _lib
+    from protocols.secure_comparison_amd.build import OUT
+
+    if shutil.which("gcc") is None:
+        import pytest
+
+        pytest.skip("no gcc here")
+    src = tmp_path / "host.c"
+    src.write_text('#include "sc_amd.h"\n#include <stdio.h>\n'
+                   'int main(void) { printf("%d\\n", sc_abi_version()); return 0; }\n')
+    exe = tmp_path / "host"
+    libdir = os.path.dirname(OUT)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L", libdir, "-lsc_amd", "-Wl,-rpath," + libdir], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    assert int(out.strip()) == _lib.ABI_VERSION
