@@ -558,6 +558,70 @@ struct Grp {
       normalize(r, sub);
     }
   }
+  // -------------------------------------------------------------------------------------------
+  // Leaving a context whose modulus is the multiple M = c n (Grp::NEG1, sc_lib.hip::neg1_twin) with a residue modulo n:
+  // for a in Z_M,  (a c) mod M = c (a mod n)  (a = r + n j  =>  a c = r c + M j, and r c < n c = M), so the out-conversion
+  // multiplies by the small factor c inside the reduction pass (redc_scaled: r = b c / R mod M, the same S^2 multiply-adds as a
+  // plain reduction plus L), the caller canonicalises modulo M, and the exact quotient by c is a mod n in [0, n) -- canonical
+  // without ever touching n (exact_div_small).
+  // -------------------------------------------------------------------------------------------
+  // r = b * scale / R mod n (lazily reduced); scale < 2^W, limbs of b < 2^(W+2): every column starts below 2^(2W+2).
+  __device__ __forceinline__ void redc_scaled(uint32_t (&r)[L], const uint32_t (&b)[L], uint32_t scale) const {
+    uint64_t T[L];
+#pragma unroll
+    for (int i = 0; i < L; i++) T[i] = (uint64_t)b[i] * scale;
+#pragma unroll 1
+    for (int k = 0; k < G; k++) {
+#pragma unroll
+      for (int l = 0; l < L; l++) {
+        const uint32_t q = bcast0<G>(NEG1 ? (uint32_t)T[l] : (uint32_t)T[l] * n0inv) & lmask_v;
+#pragma unroll
+        for (int c = 0; c < L; c++) T[(l + c) % L] += (uint64_t)q * n[c];
+        const uint64_t t0 = T[l];
+        T[(l + 1) % L] += t0 >> W;
+        T[l] = (uint64_t)(from_above_raw((uint32_t)t0) & lmask_v);
+      }
+    }
+    uint64_t c = 0;
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+      const uint64_t v = T[l] + c;
+      r[l] = (uint32_t)v & LMASK;
+      c = v >> W;
+    }
+    if constexpr (G > 1) {
+      const uint32_t clo = from_below((uint32_t)c), chi = from_below((uint32_t)(c >> 32));
+      const uint64_t v = (uint64_t)r[0] + (((uint64_t)chi << 32) | clo);
+      r[0] = (uint32_t)v & LMASK;
+      r[1] += (uint32_t)(v >> W);
+    }
+  }
+  // x <- x / c for an exact multiple x of the odd c < 2^W (x canonical: limbs < 2^W), cinv = c^-1 mod 2^W.  Least significant
+  // limb first (Jebelean): y_i = (x_i - b) c^-1 mod 2^W, and the next limb owes b = floor(y_i c / 2^W) + [x_i < b].  The chain runs
+  // through the lanes of the group in order: in phase k every lane runs its L limbs with the debt it was handed, lane k keeps the
+  // result and hands its final debt to lane k + 1 (identical instruction stream in all lanes).  b <= c < 2^W throughout.
+  __device__ __forceinline__ void exact_div_small(uint32_t (&x)[L], uint32_t c, uint32_t cinv) const {
+    uint32_t res[L], debt_in = 0;
+#pragma unroll
+    for (int l = 0; l < L; l++) res[l] = 0;
+#pragma unroll 1
+    for (int k = 0; k < G; k++) {
+      uint32_t b = debt_in, y[L];
+#pragma unroll
+      for (int l = 0; l < L; l++) {
+        const uint32_t xi = x[l];
+        const uint32_t under = (xi < b) ? 1u : 0u;
+        const uint32_t t = (xi - b) & LMASK;
+        y[l] = (t * cinv) & LMASK;
+        b = (uint32_t)(((uint64_t)y[l] * c) >> W) + under;
+      }
+#pragma unroll
+      for (int l = 0; l < L; l++) res[l] = (j == k) ? y[l] : res[l];
+      debt_in = from_below(b);
+    }
+#pragma unroll
+    for (int l = 0; l < L; l++) x[l] = res[l];
+  }
   __device__ __forceinline__ bool equal(const uint32_t (&a)[L], const uint32_t (&b)[L]) const {
     uint32_t d = 0;
 #pragma unroll

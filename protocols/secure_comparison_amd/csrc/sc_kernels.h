@@ -19,9 +19,9 @@ namespace sc {
 #define SC_L27_WAVES 2    // waves per SIMD of the L = 27 configurations (1536 / 3072 / 6144-bit moduli): 256 VGPRs, the 120 spill
                           // instructions all outside the product loops; +2 % on configs[4] with 3072-bit DGK over one wave + AGPR copies
 #endif
-template <int G, int L, int WB>
+template <int G, int L, int WB, bool NEG1 = false>
 __global__ void __launch_bounds__(64, (G == 1 && L == 37) ? 2 : (L == 27 ? SC_L27_WAVES : ((L > 18 || (G == 16 && L > 14)) ? 1 : SC_VM_WAVES))) k_vm(const VmArgs args) {
-  using GT = Grp<G, L, WB>;
+  using GT = Grp<G, L, WB, NEG1>;
   constexpr int S = GT::S, NG = GT::NG, SP = GT::SP, WP = GT::WP;
   __shared__ uint32_t s_a[NG * SP];            // per-group staging area for the LDS-side operand
   __shared__ uint32_t s_a2[G == 1 ? 1 : NG * SP];  // the same operand doubled (squarings of the multi-lane forms); also the
@@ -174,6 +174,8 @@ __global__ void __launch_bounds__(64, (G == 1 && L == 37) ? 2 : (L == 27 ? SC_L2
         }
         case OP_REDC: {
           uint32_t r[L];
+          // imm = 1 (contexts of a modulus multiple M = c n only): times the small factor c on the way out, see redc_scaled
+          if (NEG1 && imm) gp.redc_scaled(r, acc, args.small_c); else
           gp.redc(r, acc);
 #pragma unroll
           for (int l = 0; l < L; l++) acc[l] = r[l];
@@ -185,6 +187,7 @@ __global__ void __launch_bounds__(64, (G == 1 && L == 37) ? 2 : (L == 27 ? SC_L2
         }
         case OP_STOREW: {
           gp.canonical(acc);
+          if (NEG1 && imm) gp.exact_div_small(acc, args.small_c, args.small_cinv);   // c (a mod n) -> a mod n, canonical modulo n
           const VmExt& e = args.ext[op.w1 & 0xf];
           uint64_t flat = (uint64_t)op.w2 * args.count + idx;
           if (op.w3) flat = ((const uint64_t*)args.ext[(op.w3 - 1) & 0xf].ptr)[idx];   // scatter (the shuffle of step 4i); guarded by e.limit

@@ -140,6 +140,7 @@ struct Mod {
   int G = 0, L = 0, W = 29, S = 0, nwords = 0, nbits = 0;
   Big n;
   uint32_t n0inv = 0;
+  uint32_t small_c = 0, small_cinv = 0;   // a modulus multiple M = c n (neg1_twin): c and c^-1 mod 2^W, else 0
   uint32_t* d_ctx = nullptr;  // n | R^2 | R  limb form
 };
 struct Exp { Big e; int bits = 0; };
@@ -393,9 +394,9 @@ struct Builder {
   void loadt_extl(int ext, uint32_t off = 0) { emit(OP_LOADT, AK_EXTL, 0, ext, off); }
   void stt(uint32_t e) { touch(e); emit(OP_STT, 0, e); }
   void addt(uint32_t e) { touch(e); emit(OP_ADDT, 0, e); }
-  void redc() { emit(OP_REDC); redcs++; }
-  void storew(int ext, uint32_t off = 0) { emit(OP_STOREW, 0, 0, ext, off); }
-  void storew_at(int ext, int ext_index) { emit(OP_STOREW, 0, 0, ext, 0, 1 + ext_index); }   // row = ext_index[item] (u64)
+  void redc(bool times_c = false) { emit(OP_REDC, 0, times_c ? 1 : 0); redcs++; }     // times_c / over_c: leaving a modulus-multiple context (sc_vm.h)
+  void storew(int ext, uint32_t off = 0, bool over_c = false) { emit(OP_STOREW, 0, over_c ? 1 : 0, ext, off); }
+  void storew_at(int ext, int ext_index, bool over_c = false) { emit(OP_STOREW, 0, over_c ? 1 : 0, ext, 0, 1 + ext_index); }   // row = ext_index[item] (u64)
   void storel(int ext, uint32_t off = 0) { emit(OP_STOREL, 0, 0, ext, off); }
   void storeflag(int ext, uint32_t off, int lds_const) { emit(OP_STOREFLAG, 0, 0, ext, off, lds_const); }
   void end() { emit(OP_END); }
@@ -423,13 +424,13 @@ int finalize_prog(sc_ctx* ctx, const Mod& m, Builder& b, Prog* out) {
   return SC_OK;
 }
 
-template <int G, int L, int WB>
+template <int G, int L, int WB, bool NEG1 = false>
 int launch_vm_cfg(sc_ctx* ctx, const VmArgs& a, int cfg_index) {
   auto it = ctx->occ_cache.find(cfg_index);
   int occ;
   if (it == ctx->occ_cache.end()) {
     int nb = 0;
-    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_vm<G, L, WB>, 64, 0));
+    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_vm<G, L, WB, NEG1>, 64, 0));
     occ = std::max(1, std::min(nb, 16));
     ctx->occ_cache[cfg_index] = occ;
   } else {
@@ -443,7 +444,7 @@ int launch_vm_cfg(sc_ctx* ctx, const VmArgs& a, int cfg_index) {
   VmArgs args = a;
   int rc = ensure_scratch(ctx, scratch_bytes, &args.scratch);
   if (rc) return rc;
-  hipLaunchKernelGGL((k_vm<G, L, WB>), dim3(grid), dim3(64), 0, ctx->stream, args);
+  hipLaunchKernelGGL((k_vm<G, L, WB, NEG1>), dim3(grid), dim3(64), 0, ctx->stream, args);
   HIPCHK(ctx, hipGetLastError());
   return SC_OK;
 }
@@ -475,6 +476,7 @@ int run_vm(sc_ctx* ctx, int mod, const Prog& p, const VmExt* exts, int next, uin
   a.nops = p.nops;
   a.nconst_extra = p.nconst;
   a.nscratch = p.nscratch;
+  a.small_c = m.small_c; a.small_cinv = m.small_cinv;
   for (int i = 0; i < next; i++) a.ext[i] = exts[i];
   // multiply-adds issued per item: a product or a reduction pass is S^2 (S/G limb steps x L per lane x G lanes); the a*a part
   // of a squaring is L(L+1)/2 per (lane, block) pair, G^2 pairs
@@ -484,6 +486,8 @@ int run_vm(sc_ctx* ctx, int mod, const Prog& p, const VmExt* exts, int next, uin
                                         p.sqrs_per_item * (double)G * G * L * (L + 1) / 2.0);
   int rc = SC_ERR_UNSUPPORTED;
   int ci = 0;
+  // a (4,18) modulus = -1 (mod 2^29) -- in practice the multiple M = c n of neg1_twin -- runs the instance without the quotient multiply
+  if (G == 4 && L == 18 && m.W == 29 && m.n0inv == 1) return launch_vm_cfg<4, 18, 29, true>(ctx, a, 900);
 #define SC_CASE(GG, LL, WW) if (G == GG && L == LL && m.W == WW) rc = launch_vm_cfg<GG, LL, WW>(ctx, a, ci); ci++;
   SC_CASE(1, 18, 29) SC_CASE(2, 18, 29) SC_CASE(2, 27, 29) SC_CASE(4, 18, 29) SC_CASE(4, 27, 29) SC_CASE(8, 18, 29) SC_CASE(8, 27, 29)
   SC_CASE(16, 18, 29) SC_CASE(4, 14, 29) SC_CASE(8, 14, 29) SC_CASE(16, 14, 29)
@@ -1013,6 +1017,7 @@ int sc_fixedbase_pow(sc_ctx* ctx, int fbt, const uint32_t* e, int ewords, const 
   return run_vm(ctx, f.mod, it->second, ex, 3, count, f.d_rows);
 }
 
+static int neg1_vm_twin(sc_ctx* ctx, int mod, uint64_t count);
 // premul (nullable): a finished factor per item (e.g. a randomizer h^r computed ahead of time on another stream) multiplied in
 // before the store -- the alternative to the fixed-base tail (fbt / e2)
 static int modexp_var_impl(sc_ctx* ctx, int mod, const uint32_t* x, const uint32_t* e, int ewords, int ebits, int fbt,
@@ -1021,13 +1026,20 @@ static int modexp_var_impl(sc_ctx* ctx, int mod, const uint32_t* x, const uint32
   if (ctx && count == 0) return SC_OK;  // empty batch: nothing to do (pointers may be null)
   if (!valid_mod(ctx, mod) || !x || !e || !out || ewords <= 0 || ebits <= 0 || ebits > 32 * ewords)
     return fail(ctx, SC_ERR_ARG, "sc_modexp_var: bad argument");
-  const Mod& m = ctx->mods[mod];
   const Fbt* f = nullptr;
   if (fbt >= 0) {
     if (fbt >= (int)ctx->fbts.size() || ctx->fbts[fbt].mod != mod || !e2 || e2words <= 0) return fail(ctx, SC_ERR_ARG, "sc_modexp_var: bad fixed-base table");
     f = &ctx->fbts[fbt];
   }
-  std::string key = "mvar:" + std::to_string(mod) + ":" + std::to_string(ebits) + ":" + std::to_string(fbt) + (dest ? ":s" : "") + (premul ? ":p" : "");
+  // chip-filling batches of a (4,18) modulus run in the context of its multiple M = c n = -1 (mod 2^29) (no quotient multiply per
+  // limb step): inputs, constants and table rows are residues modulo n and therefore valid modulo M as they are; the program
+  // leaves through the reduction pass times c and the exact division by c (sc_device.h).  Not with premul: that variant leaves
+  // Montgomery form through a product, which has no room for the factor c.
+  const int tmod = premul ? -1 : neg1_vm_twin(ctx, mod, count);
+  const bool twin = tmod >= 0;
+  const int rmod = twin ? tmod : mod;
+  const Mod& m = ctx->mods[mod];        // (taken after the twin exists: creating it may move the table of moduli)
+  std::string key = "mvar:" + std::to_string(rmod) + ":" + std::to_string(ebits) + ":" + std::to_string(fbt) + (dest ? ":s" : "") + (premul ? ":p" : "");
   auto it = ctx->progs.find(key);
   if (it == ctx->progs.end()) {
     const int w = ebits <= 4 ? 1 : (ebits <= 12 ? 2 : 3);
@@ -1039,16 +1051,16 @@ static int modexp_var_impl(sc_ctx* ctx, int mod, const uint32_t* x, const uint32
     bd.loadt_tbldig(1, (nd - 1) * w, w, 0);
     for (int d = nd - 2; d >= 0; d--) { for (int k = 0; k < w; k++) bd.sqr(); bd.mul_tbldig(1, d * w, w, 0); }
     if (f) for (int j = 0; j < f->nwin; j++) bd.mul_fbt(3, j * f->window, f->window, j);
-    if (premul) bd.mul_extw(5); else bd.redc();          // (x^e R) * premul / R = x^e premul: leaves Montgomery form by itself
-    if (dest) bd.storew_at(2, 4); else bd.storew(2);
+    if (premul) bd.mul_extw(5); else bd.redc(twin);      // (x^e R) * premul / R = x^e premul: leaves Montgomery form by itself
+    if (dest) bd.storew_at(2, 4, twin); else bd.storew(2, 0, twin);
     bd.end();
-    Prog p; int rc = finalize_prog(ctx, m, bd, &p); if (rc) return rc;
+    Prog p; int rc = finalize_prog(ctx, ctx->mods[rmod], bd, &p); if (rc) return rc;
     it = ctx->progs.emplace(key, p).first;
   }
   // a scattered store never leaves the output array: rows >= count are dropped by the limit of the output operand
   VmExt ex[6] = {mk_ext(x, m.nwords, m.nwords), mk_ext(e, ewords, ewords), mk_ext(out, m.nwords, m.nwords, dest ? count : ~0ull),
                  mk_ext(e2, e2words, e2words), mk_ext(dest, 2, 2), mk_ext(premul, m.nwords, m.nwords)};
-  return run_vm(ctx, mod, it->second, ex, 6, count, f ? f->d_rows : nullptr);
+  return run_vm(ctx, rmod, it->second, ex, 6, count, f ? f->d_rows : nullptr);
 }
 
 int sc_modexp_var(sc_ctx* ctx, int mod, const uint32_t* x, const uint32_t* e, int ewords, int ebits, int fbt,
@@ -1537,10 +1549,26 @@ static int neg1_twin(sc_ctx* ctx, int mod) {
       const Config same = {m.G, m.L, m.W, false};
       if (create_mod(ctx, M.data(), (int)M.size(), false, &twin, &same) != SC_OK) twin = -1;
       if (twin >= 0 && ctx->mods[twin].n0inv != 1) twin = -1;     // (cannot happen: M = -1 mod 2^29 by construction)
+      if (twin >= 0) {           // what a single-modulus program needs to leave the context with a residue modulo n (sc_vm.h)
+        uint32_t inv = m.n0inv;                                    // c is odd: c c = 1 (mod 8); Newton doubles the good bits
+        for (int it = 0; it < 5; it++) inv *= 2u - m.n0inv * inv;
+        ctx->mods[twin].small_c = m.n0inv;
+        ctx->mods[twin].small_cinv = inv & ((1u << m.W) - 1);
+      }
     }
   }
   ctx->neg1_twins[mod] = twin;
   return twin;
+}
+
+// The same twin for the single-modulus interpreter: only the (4,18) instance k_vm<4,18,29,true> exists, and only programs whose
+// outputs are word stores can use it (modexp_var_impl: the blinding launch of step 4i) -- limb-form outputs would carry residues
+// up to 2M into launches of the original context.
+static int neg1_vm_twin(sc_ctx* ctx, int mod, uint64_t count) {
+  const Mod& m = ctx->mods[mod];
+  if (m.W != 29 || m.L != 18 || m.G != 4 || use_latency_config(ctx, m, count)) return -1;
+  const int t = neg1_twin(ctx, mod);
+  return (t >= 0 && ctx->mods[t].small_c != 0) ? t : -1;
 }
 
 // The one-lane twin of `mod` when this batch should run on it, else `mod` itself.  Automatic policy: the modulus fits the

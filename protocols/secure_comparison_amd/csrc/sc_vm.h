@@ -15,8 +15,9 @@ enum VmOpcode : uint32_t {
   OP_LOADW = 2,      // ACC = words  ext[w1] at (off = w2), word offset w3>>16, nwords w3&0xffff (0 = ext default)
   OP_ADDW = 3,       // ACC += words (same addressing as LOADW), lazy limb-wise add
   OP_LOADT = 4,      // ACC = limb-form operand given by akind (table / const / fbt / ext-limbs)
-  OP_REDC = 5,       // ACC = ACC / R mod n
-  OP_STOREW = 6,     // canonical(ACC) -> words ext[w1] at off w2; w3 != 0: at the flat item index ext[w3-1][item] (u64) instead
+  OP_REDC = 5,       // ACC = ACC / R mod n;  imm = 1 (modulus-multiple contexts): ACC = ACC c / R mod M
+  OP_STOREW = 6,     // canonical(ACC) -> words ext[w1] at off w2; w3 != 0: at the flat item index ext[w3-1][item] (u64) instead;
+                     //   imm = 1 (modulus-multiple contexts): canonical(ACC) / c exactly, i.e. the residue modulo n
   OP_STOREFLAG = 7,  // (canonical(ACC) == const[w3]) -> u8 ext[w1] at off w2;  imm != 0: OR the flag into the u64 ext[w1][item mod ext.stride64]
                      //   instead (ext.limit = inner count): one flag per group of items, e.g. delta_B = OR over the l+1 zero tests
   OP_STT = 8,        // scratch[imm] = ACC
@@ -81,6 +82,7 @@ struct VmArgs {
   uint32_t nops;
   uint32_t nconst_extra;
   uint32_t nscratch;
+  uint32_t small_c, small_cinv;   // contexts of a modulus multiple M = c n: c and c^-1 mod 2^W (OP_REDC / OP_STOREW with imm = 1)
   VmExt ext[VM_MAX_EXT];
 };
 

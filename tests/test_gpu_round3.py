@@ -411,3 +411,37 @@ def test_deferred_inversion_verdicts_still_name_the_element(engine, keys):
     assert torch.equal(again, good)
     dec = bob_p.decrypt_raw_batch(again)
     assert bool((dec[:, 0] == (x <= y).to(torch.int32)).all().item())
+
+
+@pytest.mark.parametrize("nbits", [2048, 2041])
+def test_blinding_launch_in_the_modulus_multiple_context(engine, nbits):
+    """sc_modexp_var above 8192 items of a (4,18) modulus runs modulo M = c n = -1 (mod 2^29) and leaves through the scaled
+    reduction and the exact division by c (sc_device.h: redc_scaled / exact_div_small): results must be the canonical residues
+    modulo n -- for edge operands (0, 1, n - 1, n - 2, values whose power is n - 1), random ones, with and without the fixed-base
+    tail, in place and scattered.  A second modulus length moves the limb boundaries of M."""
+    rng = random.Random(4100 + nbits)
+    n = rng.getrandbits(nbits) | (1 << (nbits - 1)) | 1
+    while (-pow(n, -1, 1 << 29)) % (1 << 29) == 1:        # (a modulus that is -1 already needs no multiple)
+        n += 2
+    mod = engine.modulus(n)
+    count = 9001                                          # > 8192: not the small-batch configuration; a partially filled last wave
+    xs = [0, 1, n - 1, n - 2, 2, (n - 1) // 2] + [rng.randrange(n) for _ in range(count - 6)]
+    es = [1, 3, 1, 2, (1 << 34) - 1, 7] + [rng.randrange(1, 1 << 34) for _ in range(count - 6)]
+    es[2] = 1                                             # (n - 1)^1 = n - 1: the largest canonical result, X = c (n - 1)
+    es[3] = 2
+    tx, te = engine.upload(xs, mod.nwords), engine.upload(es, 2)
+    assert engine.download(engine.modexp_var(mod, tx, te, 34)) == [pow(x, e, n) for x, e in zip(xs, es)]
+    h = rng.randrange(2, n)
+    fb = engine.fixed_base(mod, h, 400, window=8)
+    rs = [0, 1, (1 << 400) - 1] + [rng.getrandbits(400) for _ in range(count - 3)]
+    tr = engine.upload(rs, 13)
+    expect = [pow(x, e, n) * pow(h, r, n) % n for x, e, r in zip(xs, es, rs)]
+    assert engine.download(engine.modexp_var(mod, tx, te, 34, fb, tr)) == expect
+    perm = list(range(count))
+    rng.shuffle(perm)
+    dest = torch.tensor(perm, dtype=torch.int64, device=engine.device)
+    got = engine.download(engine.modexp_var(mod, tx, te, 34, fb, tr, dest=dest))
+    assert [got[perm[i]] for i in range(count)] == expect
+    # the same numbers below the threshold (small-batch configuration, original modulus): equal results
+    small = 500
+    assert engine.download(engine.modexp_var(mod, tx[:small].contiguous(), te[:small].contiguous(), 34, fb, tr[:small].contiguous())) == expect[:small]
