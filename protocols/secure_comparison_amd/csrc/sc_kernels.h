@@ -306,9 +306,15 @@ __global__ void __launch_bounds__(64, ((G == 16 && L > 9) ? 1 : SC_PVM_WAVES)) k
 #pragma unroll
     for (int l = 0; l < L; l++) { x0[l] = 0; x1[l] = 0; }
 
+    // G <= 2 (the half-size moduli: a pair squaring is half as long as at G = 4): the next micro-op is fetched -- a scalar load --
+    // while this one runs, its latency hides behind the staging of the operands.  Measured on the MI355X, alternating builds:
+    // x^p mod p^2 on k_pvm<2,18> 43.4 -> 43.0 ms, the key holder's decryption 29.5 -> 29.3 ms; k_pvm<4,18> 104.25 -> 104.5 ms, hence not there.
+    constexpr bool PREFETCH_OP = (G <= 2);
+    VmOp nxt = args.prog[0];
 #pragma unroll 1
     for (uint32_t pc = 0; pc < args.nops; pc++) {
-      const VmOp op = args.prog[pc];
+      VmOp op;
+      if constexpr (PREFETCH_OP) { op = nxt; nxt = args.prog[pc + 1 < args.nops ? pc + 1 : pc]; } else { op = args.prog[pc]; }
       const uint32_t opc = op.w0 & 0xff;
       switch (opc) {
         case PV_LOADU: {
