@@ -5,6 +5,7 @@
 #include <sys/random.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -1572,8 +1573,8 @@ static int neg1_vm_twin(sc_ctx* ctx, int mod, uint64_t count) {
 }
 
 // The one-lane twin of `mod` when this batch should run on it, else `mod` itself.  Automatic policy: the modulus fits the
-// one-lane configuration and the batch is at least one and a half rounds of the chip's resident one-lane waves (2 per SIMD, 64
-// numbers each: 196608 numbers on 256 CUs).  Measured on the MI355X (1024-bit modulus, 1024-bit exponent): 196608 numbers 19.8 ->
+// one-lane configuration and a model of the two forms' run times in rounds of the chip's resident one-lane waves (2 per SIMD, 64
+// numbers each: 131072 numbers on 256 CUs) says the one-lane form is faster (round 2: a fixed threshold of one and a half rounds).  Measured on the MI355X (1024-bit modulus, 1024-bit exponent): 196608 numbers 19.8 ->
 // 16.6 ms, 2.1 M numbers (zero tests) 37.3 -> 33.0 ms, but 98304 numbers 9.5 -> 11.6 ms -- three quarters of a round leaves a
 // quarter of the SIMDs with one wave and nobody to hide its latencies, where the two-lane form still runs 1.5 full rounds.
 // When several contexts work on the GPU at once (concurrent shards: sc_ctx_set_chip_share) a launch owns its share of the chip
@@ -1585,7 +1586,20 @@ static int onelane_for(sc_ctx* ctx, int mod, uint64_t count) {
     const Mod& m = ctx->mods[mod];
     // the residue arrays (and the raw chunks a wide operand is read in) must fit below R = 2^(28 * 37): at most 32 words
     if (m.W == kOneLane.W || m.nbits + 8 > kOneLane.W * kOneLane.G * kOneLane.L || 32 * m.nwords > kOneLane.W * kOneLane.G * kOneLane.L) return mod;
-    if (ctx->onelane_mode == 1 && count < (uint64_t)ctx->num_cu * 4 * 2 * 64 * 3 / 2 / (uint64_t)ctx->chip_share) return mod;
+    if (ctx->onelane_mode == 1) {
+      // Both forms run in rounds of their resident waves on this context's share of the chip: 131072 numbers per one-lane round
+      // (2 waves x 64 numbers per SIMD), 65536 per two-lane round.  Measured run times in units of a full one-lane round (x^e mod p,
+      // 1024 bits, 11.05 ms; tools/gpu_onelane_sweep.py, profiles/r03_onelane_policy_sweep.txt): one-lane 1.0 per full round and for a
+      // last round above half, 0.5 for a last round that leaves every SIMD at most one wave; two-lane 0.6 per full round and for a last
+      // round above half, 0.27 up to half (0.38 when it is the only round).  The faster form by that model runs (round 2: one-lane
+      // from one and a half rounds, which sent e.g. 131072 numbers to the two-lane form: 13.3 instead of 11.1 ms).
+      const double share = (double)ctx->chip_share / ((double)ctx->num_cu * 4 * 2 * 64);
+      const double r1 = (double)count * share, r2 = 2.0 * r1;
+      const double f1 = r1 - std::floor(r1), f2 = r2 - std::floor(r2);
+      const double one = std::floor(r1) + (f1 <= 0.0 ? 0.0 : (f1 <= 0.5 ? 0.5 : 1.0));
+      const double two = 0.6 * std::floor(r2) + (f2 <= 0.0 ? 0.0 : (f2 <= 0.5 ? (r2 < 1.0 ? 0.38 : 0.27) : 0.6));
+      if (one >= two) return mod;
+    }
   }
   auto it = ctx->onelane_twins.find(mod);
   if (it != ctx->onelane_twins.end()) return it->second < 0 ? mod : it->second;
