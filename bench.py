@@ -228,6 +228,12 @@ def interactive_protocol_leg(torch, eng, parties, ns, shard_inputs, x_enc, y_enc
                 "(InMemoryCommunicator.device_tensors); informational, never `value`"}
 
 
+def workload_name(B, l, pbits, dbits):
+    cfg = {(65536, 32, 2048): "BASELINE configs[2]", (4096, 16, 2048): "BASELINE configs[1]", (131072, 32, 2048): "per-GPU share of BASELINE configs[3]",
+           (32768, 64, 3072): "per-GPU share of BASELINE configs[4]"}.get((B, l, pbits), "custom")
+    return "batch %d comparisons per GPU, l=%d, %d-bit Paillier + %s DGK (%s)" % (B, l, pbits, "%d-bit" % dbits if dbits else "default", cfg)
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -242,15 +248,16 @@ def parse_args(argv=None):
     ap.add_argument("--no-crt", action="store_true")
     ap.add_argument("--no-shuffle", action="store_true", help="leave the step-4i permutation out (do_shuffle=False)")
     ap.add_argument("--streams", type=int, default=0, help="concurrent shards per GPU (one library context, HIP stream and host thread each); 1 = a single stream; "
-                    "0 = automatic: 2 from 32768 comparisons of 2048-bit keys per GPU (scaled by the square of the key size)")
+                    "0 = automatic: 2 once every shard's widest launches still fill the chip (128 comparisons of 2048-bit keys per CU and shard, scaled by the square of the key size)")
     ap.add_argument("--side-stream", type=int, default=-1, help="run the randomizer exponentiations of a step on a second library context and stream per shard, "
-                    "concurrently with the protocol's critical path (batch._AheadOfTime): 1 on, 0 off, -1 automatic (on up to 8192 comparisons per GPU: measured +15 % at 4096, -2 % at 16384)")
+                    "concurrently with the protocol's critical path (batch._AheadOfTime): 1 on, 0 off, -1 automatic (on while the batch leaves most wave slots empty: up to 32 comparisons per CU; measured +15 % at 4096, -2 % at 16384 on 256 CUs)")
     ap.add_argument("--side-fork", type=int, default=0, help="fork mode (sc_ctx_set_fork_mode) of the second contexts")
     ap.add_argument("--latency-mode", type=int, default=1, help="small-batch kernel policy (sc_ctx_set_latency_mode): 0 never, 1 automatic, 2 always")
     ap.add_argument("--onelane-mode", type=int, default=1, help="large-batch kernel policy for the 1024-bit primes (sc_ctx_set_onelane_mode): 0 never, 1 automatic, 2 always")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0)
     ap.add_argument("--no-extras", action="store_true", help="skip the informational legs (window sensitivity, online phase, PCIe-inclusive)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the compact sub-lines of BASELINE configs[1] and the configs[4] per-GPU share")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (exercises the RCCL path)")
     ap.add_argument("--c-abi-gather", action="store_true", help="after the timed region, repeat the reassembly through the C ABI's own RCCL communicator "
                     "(sc_comm_init / sc_allgather) and report whether it equals torch.distributed's gather")
@@ -270,13 +277,6 @@ def main() -> None:
 
     import torch
 
-    from protocols.secure_comparison_amd import DGK, Paillier
-    from protocols.secure_comparison_amd.batch import (BatchDraws, ConcurrentShards, PartySet, boot_pools, secure_comparison_batch,
-                                                       split_draws)
-    from protocols.secure_comparison_amd.distributed import shard_bounds
-    from protocols.secure_comparison_amd.engine import Engine
-    from protocols.secure_comparison_amd.schemes import default_engine
-
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but this node shows {torch.cuda.device_count()} GPU(s) (no CPU fallback)")
     if not torch.cuda.is_available():
@@ -292,6 +292,24 @@ def main() -> None:
         # a rank that never arrives must not hang the others for torch's default half hour
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
                                 timeout=datetime.timedelta(seconds=int(os.environ.get("SC_AMD_RENDEZVOUS_TIMEOUT_S", launcher.RENDEZVOUS_TIMEOUT_S))))
+    line = measure(args, torch, dist, rank, world, full=True)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def measure(args, torch, dist, rank: int, world: int, full: bool):
+    """One configuration: set-up, warm-up, the timed steps, and (rank 0) the line's content.  full: the headline run with every
+    diagnostic and informational leg; otherwise a compact sub-line (value, ms per step, whole-step fraction) of another BASELINE shape
+    measured by the same code path."""
+    from protocols.secure_comparison_amd import DGK, Paillier, launcher
+    from protocols.secure_comparison_amd.batch import (BatchDraws, ConcurrentShards, PartySet, boot_pools, secure_comparison_batch,
+                                                       split_draws)
+    from protocols.secure_comparison_amd.distributed import shard_bounds
+    from protocols.secure_comparison_amd.engine import Engine
+    from protocols.secure_comparison_amd.schemes import default_engine
 
     keys = json.load(open(KEYS))
     l, B = args.l, args.batch
@@ -302,12 +320,16 @@ def main() -> None:
     p, q = int(pj["p"], 16), int(pj["q"], 16)
     H = lambda name: int(dj[name], 16)  # noqa: E731
     use_crt = not args.no_crt
-    eng = default_engine()
-    # two concurrent shards pay from about 32768 comparisons of 2048-bit keys per GPU (+1.4 % there, +5 % at 65536, +7 % at the
-    # 3072-bit configs[4] share of 32768); the weight of a comparison grows with the square of the key size
-    ns = max(1, min(args.streams, B)) if args.streams > 0 else (2 if B * (args.pbits / 2048.0) ** 2 >= 32768 else 1)
+    eng = default_engine() if full else Engine()
+    props = torch.cuda.get_device_properties(eng.device)
+    cus = props.multi_processor_count
+    # Two concurrent shards pay once each shard's widest launches still fill the chip by themselves: a pair launch holds 16 items per
+    # wave and 8 waves per CU, so 128 comparisons of 2048-bit keys per CU and shard (256 CUs: from 32768 comparisons per GPU, +1.4 %
+    # there, +5 % at 65536, +7 % at the 3072-bit configs[4] share of 32768); the weight of a comparison grows with the square of the
+    # key size.  The randomizers move to a second context while the batch leaves most wave slots empty (up to 32 comparisons per CU).
+    ns = max(1, min(args.streams, B)) if args.streams > 0 else (2 if B * (args.pbits / 2048.0) ** 2 >= 128 * cus else 1)
     ns = launcher.host_threads_per_rank(world, ns)      # shard threads of all ranks together stay within the node's cores
-    use_side = bool(args.side_stream) if args.side_stream >= 0 else (B <= 8192)
+    use_side = bool(args.side_stream) if args.side_stream >= 0 else (B <= 32 * cus)
     engines = [eng] + [Engine() for _ in range(1, ns)]
     side_engines = [Engine() for _ in range(ns)] if use_side else []
     for e_ in engines + side_engines:
@@ -360,31 +382,44 @@ def main() -> None:
         shard_inputs = [(x_enc[a:b].contiguous(), y_enc[a:b].contiguous(), d) for (a, b), d in zip(bounds, split_draws(draws, bounds))]
         torch.cuda.synchronize()
 
+    # persistent result arrays: every shard writes its rows into its block of `result_buf` (no concatenation pass inside a step),
+    # and the per-step all-gather fills the same `gather_buf` every time
+    result_buf = torch.empty((B, 2 * alice_p.mod_n.nwords), dtype=torch.int32, device=eng.device)
+    gather_buf = None if dist is None else torch.empty((world * B, result_buf.shape[1]), dtype=torch.int32, device=eng.device)
+
     def make_step(party_sets):
         """(step function, closer): the closer ends the shard threads and hands the chip back to single-stream policies."""
         if ns == 1:
             ps = party_sets[0]
             return (lambda: secure_comparison_batch(x_enc, y_enc, l, ps.alice_paillier, ps.alice_dgk, ps.bob_paillier, ps.bob_dgk, draws,
-                                                    randomize=True, side=ps.side)), (lambda: None)
+                                                    randomize=True, side=ps.side, out=result_buf)), (lambda: None)
         runner = ConcurrentShards(party_sets)
-        return (lambda: torch.cat(runner.run(shard_inputs, l, randomize=True), dim=0)), runner.close
+        return (lambda: runner.run(shard_inputs, l, randomize=True, out=result_buf)), runner.close
 
     step, close_step = make_step(parties)
 
     def gather(res):
         if dist is None:
             return res
-        out = torch.empty((world * res.shape[0], res.shape[1]), dtype=res.dtype, device=res.device)
-        dist.all_gather_into_tensor(out, res.contiguous())
-        return out
+        dist.all_gather_into_tensor(gather_buf, res)
+        return gather_buf
 
-    def timed(fn, steps):
+    def timed(fn, steps, marks=None):
+        """`steps` steps between two barrier + synchronize brackets; the time is the maximum over the ranks.  marks: a list that
+        receives one event per step boundary (recorded on the caller's stream, which waits for the shard streams at the end of
+        every step: no synchronisation is added) -- the per-step spread is read from them afterwards."""
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        if marks is not None:
+            marks.append(torch.cuda.Event(enable_timing=True))
+            marks[-1].record()
         for _ in range(steps):
             r_ = gather(fn())
+            if marks is not None:
+                marks.append(torch.cuda.Event(enable_timing=True))
+                marks[-1].record()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -394,6 +429,35 @@ def main() -> None:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, r_
+
+    def dominant_launch(reps=3):
+        """Alice's rho^N mod N^2 for the whole batch alone on the chip (k_pvm<4,18> + the assembly launch): seconds per launch by HIP
+        events on the stream the library launches on, executed multiply-adds per launch, the pure multiply-add probe's rate."""
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        alice_p.randomize_batch(x_enc, draws.rho_z)
+        torch.cuda.synchronize()
+        before = eng.mac_counter()
+        ev0.record()
+        for _ in range(reps):
+            alice_p.randomize_batch(x_enc, draws.rho_z)
+        ev1.record()
+        torch.cuda.synchronize()
+        return ev0.elapsed_time(ev1) * 1e-3 / reps, (eng.mac_counter() - before) / reps, eng.peak_probe()
+
+    def clock_ghz():
+        """Engine clock the dominant pair launch holds, from the stamping twin of the kernel (sc_clock_probe; None where the batch
+        does not take the (4,18) modulus-multiple launch)."""
+        try:
+            return eng.clock_probe(alice_p.key, draws.rho_z)[0]
+        except Exception:
+            return None
+
+    # ---- diagnostics BEFORE anything else has loaded the chip (rank 0 of the headline run): the dominant launch, the probe and the
+    # in-kernel clock -- repeated after the timed loop, so that the line itself says whether the chip's clock state moved
+    diag_before = None
+    if full and rank == 0:
+        ls_, _, pk_ = dominant_launch(reps=2)
+        diag_before = {"launch_ms": ls_ * 1e3, "probe_peak": pk_ / 1e12, "clock_ghz": clock_ghz()}
 
     res = None
     for _ in range(args.warmup):
@@ -419,12 +483,26 @@ def main() -> None:
         if rccl_ranks != world:
             raise SystemExit(f"bench.py: the all-reduce saw {rccl_ranks} ranks, expected {world}")
     [e_.mac_counter(reset=True) for e_ in engines + side_engines]
-    elapsed, res = timed(step, args.steps)
+    marks = []
+    elapsed, res = timed(step, args.steps, marks)
     executed_macs = sum(e_.mac_counter() for e_ in engines + side_engines)
     value = world * B * args.steps / elapsed
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1))
     if not all_correct(res):
         raise SystemExit("bench.py: decrypted results of the timed steps differ from x <= y")
     close_step()      # the single-stream measurements below run with the policies of a context that has the chip to itself
+    nominal_peak = cus * 64 * MAX_CLOCK_HZ   # 4 SIMDs x 16 lanes per CU, one multiply-add per lane and cycle
+    if not full:      # a compact sub-line of another BASELINE shape
+        sub = None
+        if rank == 0:
+            sub = {"workload": workload_name(B, l, args.pbits, dbits), "value": value, "unit": "comparisons/s", "ms_per_step": elapsed / args.steps * 1e3,
+                   "steps": args.steps, "streams_per_gpu": ns, "randomizers_on_side_stream": use_side, "dgk_key": dname,
+                   "whole_step_frac": executed_macs / (elapsed * nominal_peak), "all_rows_decrypt_to_x_le_y": True}
+        del parties, step, close_step
+        for e_ in engines + side_engines:
+            e_.close()
+        torch.cuda.empty_cache()
+        return sub
     # outside the timed region: the same reassembly through the C ABI's own RCCL communicator (sc_comm_init / sc_allgather,
     # what a host without torch would call), compared with torch.distributed's gather.  Opt-in (--c-abi-gather: a second
     # communicator's rendezvous is not something the scaling run should depend on); reported, never fatal.
@@ -448,19 +526,9 @@ def main() -> None:
     if rank == 0:
         # ---- roofline of the dominant kernel: Alice's Paillier randomizer rho^N mod N^2 (k_pvm<4,18> + assembly launch),
         # timed with HIP events on the stream the library launches on (torch's current stream here)
-        reps = 3
+        launch_s, launch_exec_macs, peak = dominant_launch(reps=3)
+        diag_after = {"launch_ms": launch_s * 1e3, "probe_peak": peak / 1e12, "clock_ghz": clock_ghz()}
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        z_dummy = x_enc
-        alice_p.randomize_batch(z_dummy, draws.rho_z)
-        torch.cuda.synchronize()
-        eng.mac_counter(reset=True)
-        ev0.record()
-        for _ in range(reps):
-            alice_p.randomize_batch(z_dummy, draws.rho_z)
-        ev1.record()
-        torch.cuda.synchronize()
-        launch_s = ev0.elapsed_time(ev1) * 1e-3 / reps
-        launch_exec_macs = eng.mac_counter() / reps
         s32 = 2 * args.pbits // 32
         alg_macs = B * (args.pbits + -(-args.pbits // 5) + 30 + 1) * (2 * s32 * s32 + s32)
         alg_bytes_launch = B * (args.pbits // 8 + 2 * (2 * args.pbits // 8))      # rho in, ciphertext in, ciphertext out
@@ -473,26 +541,23 @@ def main() -> None:
         ev1.record()
         torch.cuda.synchronize()
         d_rate = d_exps.shape[0] / (ev0.elapsed_time(ev1) * 1e-3)
-        peak = eng.peak_probe()
-        props = torch.cuda.get_device_properties(eng.device)
-        nominal_peak = props.multi_processor_count * 64 * MAX_CLOCK_HZ   # 4 SIMDs x 16 lanes per CU, one multiply-add per lane and cycle
         lit = literal_macs_per_comparison(l, args.pbits, dbits, args.rbits)
         abytes = algorithmic_bytes_per_comparison(l, args.pbits, dbits, args.rbits)
         # HBM traffic of the dominant launch from the committed PMC pass (rocprofv3 cannot run inside this process)
         traffic = None
-        for name in ("r03_dominant_kernel_traffic.json", "r02_dominant_kernel_traffic.json", "r01_dominant_kernel_traffic.json"):
+        for name in ("r04_dominant_kernel_traffic.json", "r03_dominant_kernel_traffic.json", "r02_dominant_kernel_traffic.json", "r01_dominant_kernel_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tpath) and B == 65536 and args.pbits == 2048 and l == 32 and use_crt:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
                 break
-        cfg_name = {(65536, 32, 2048): "BASELINE configs[2]", (4096, 16, 2048): "BASELINE configs[1]", (131072, 32, 2048): "per-GPU share of BASELINE configs[3]",
-                    (32768, 64, 3072): "per-GPU share of BASELINE configs[4]"}.get((B, l, args.pbits), "custom")
         out = {
             "metric": "secure comparisons/sec (l=%d, %d-bit keys)" % (l, args.pbits), "value": value, "unit": "comparisons/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 (29-bit limbs held in u32, 32x32+64->64 multiply-accumulate)",
             "data": "synthetic", "rccl_ranks": rccl_ranks, "rank_devices": devices, "c_abi_gather": c_abi_gather,
-            "config": {"workload": "batch %d comparisons per GPU, l=%d, %d-bit Paillier + %d-bit DGK (%s)" % (B, l, args.pbits, dbits, cfg_name),
+            "step_ms": {"min": step_ms[0], "median": step_ms[len(step_ms) // 2], "max": step_ms[-1],
+                        "note": "per-step device time between events on the caller's stream inside the timed region (no synchronisation added)"},
+            "config": {"workload": workload_name(B, l, args.pbits, dbits),
                        "batch_per_gpu": B, "l": l, "paillier_bits": args.pbits, "dgk_bits": dbits, "dgk_key": dname, "dgk_randomizer_bits": args.rbits,
                        "fixed_base_window": args.fb_window, "keyholder_crt": use_crt, "shuffle_4i": not args.no_shuffle,
                        "parallelism": "shard%d" % world, "streams_per_gpu": ns, "randomizers_on_side_stream": use_side,
@@ -517,7 +582,14 @@ def main() -> None:
                          "traffic_note": "HBM bytes moved per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from the committed PMC passes (profiles/; gfx950 tallies each 128-B line request at 64 B, "
                                          "calibrated on this library's limb rows in profiles/r01_traffic_calibration.json); it exceeds the algorithmic bytes because each item's "
                                          "window table lives in an HBM scratch arena (DESIGN.md 4)",
-                         "launch_ms": launch_s * 1e3},
+                         "launch_ms": launch_s * 1e3,
+                         "launch_ms_before": diag_before["launch_ms"], "launch_ms_after": diag_after["launch_ms"],
+                         "probe_peak_before": diag_before["probe_peak"], "probe_peak_after": diag_after["probe_peak"],
+                         "clock_ghz_before": diag_before["clock_ghz"], "clock_ghz_after": diag_after["clock_ghz"],
+                         "before_after_note": "the dominant launch, the pure multiply-add probe and the in-kernel clock (sc_clock_probe: s_memtime / s_memrealtime stamps of a twin "
+                                              "of the kernel, never a timed launch) measured BEFORE the warm-up and AFTER the timed loop: a line whose value moved "
+                                              "while these did not has changed code, one where they moved together has a chip in another clock state"},
+            "policy": eng.policy(),
             "modexp_per_s": {"P": B / launch_s, "D": d_rate,
                              "shapes": "P: %d-bit base ^ %d-bit exponent mod %d-bit (rho^N mod N^2); D: fixed base, %d-bit exponent mod %d-bit (h^r mod n)"
                                        % (args.pbits, args.pbits, 2 * args.pbits, args.rbits, dbits)},
@@ -611,10 +683,23 @@ def main() -> None:
                 del dv, d2
             out["pcie_inclusive"] = {"value": B / pcie_s, "unit": "comparisons/s", "host_bytes_per_comparison":
                                      sum(t.numel() * t.element_size() for t in host_in) / B + r2.shape[-1] * 4}
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        if not args.no_other_configs and world == 1 and (B, l, args.pbits) == (65536, 32, 2048):
+            # ---- the other BASELINE shapes that fit one GPU, by the same code path, so that they are driver-run numbers too
+            import copy
+
+            others = []
+            for kw in ({"batch": 4096, "l": 16, "pbits": 2048, "dgk": "dgk_2048_l16", "steps": 10, "warmup": 2},
+                       {"batch": 32768, "l": 64, "pbits": 3072, "dgk": "dgk_2048_l64", "steps": 2, "warmup": 1}):
+                a2 = copy.copy(args)
+                for k_, v_ in kw.items():
+                    setattr(a2, k_, v_)
+                a2.streams, a2.side_stream = 0, -1
+                try:
+                    others.append(measure(a2, torch, None, 0, 1, full=False))
+                except Exception as exc:  # pragma: no cover
+                    others.append({"workload": workload_name(kw["batch"], kw["l"], kw["pbits"], None), "error": str(exc)[:200]})
+            out["other_configs"] = others
+    return out
 
 
 if __name__ == "__main__":

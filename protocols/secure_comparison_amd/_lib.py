@@ -7,7 +7,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SC_AMD_LIB", os.path.join(HERE, "libsc_amd.so"))  # override only for A/B experiments
 
-# every symbol include/sc_amd.h declares (tests check that the library exports all of them)
+# every symbol include/sc_amd.h and include/sc_amd_dev.h declare (tests check that the library exports all of them)
 SYMBOLS = [
     "sc_ctx_create", "sc_ctx_destroy", "sc_ctx_set_stream", "sc_ctx_synchronize", "sc_last_error", "sc_last_bad_index", "sc_abi_version",
     "sc_malloc", "sc_free", "sc_memcpy_h2d", "sc_memcpy_d2h",
@@ -16,13 +16,13 @@ SYMBOLS = [
     "sc_modinv", "sc_paillier_encrypt_raw", "sc_paillier_encrypt_raw_neg", "sc_paillier_l_mul", "sc_crt_combine", "sc_plain_alice", "sc_plain_bob", "sc_dgk_step4",
     "sc_paillier_key_create", "sc_paillier_key_mods", "sc_paillier_encrypt", "sc_paillier_randomize", "sc_paillier_decrypt",
     "sc_dgk_key_create", "sc_dgk_key_info", "sc_dgk_randomize", "sc_dgk_encrypt_bits_randomized", "sc_dgk_is_zero", "sc_dgk_any_zero",
-    "sc_initiator_step1", "sc_keyholder_step2_4b", "sc_initiator_step4", "sc_initiator_step4i", "sc_keyholder_step4j_5", "sc_initiator_step67", "sc_ctx_check",
+    "sc_initiator_step1", "sc_keyholder_step2_4b", "sc_initiator_step4", "sc_initiator_step4i", "sc_keyholder_step4j_5", "sc_initiator_step67",
     "sc_rng_seed", "sc_rng_bits", "sc_rng_below", "sc_rng_coins", "sc_rng_permutations",
-    "sc_peak_probe", "sc_mac_counter", "sc_table_traffic_probe", "sc_ctx_set_latency_mode", "sc_ctx_set_onelane_mode", "sc_ctx_set_chip_share", "sc_ctx_set_fork_mode", "sc_comm_unique_id", "sc_comm_init", "sc_allgather", "sc_comm_destroy",
+    "sc_peak_probe", "sc_mac_counter", "sc_table_traffic_probe", "sc_ctx_set_latency_mode", "sc_ctx_set_onelane_mode", "sc_ctx_set_chip_share", "sc_ctx_set_fork_mode", "sc_ctx_policy", "sc_clock_probe", "sc_comm_unique_id", "sc_comm_init", "sc_allgather", "sc_comm_destroy",
 ]
 
 
-ABI_VERSION = 3   # SC_ABI_VERSION of include/sc_amd.h
+ABI_VERSION = 4   # SC_ABI_VERSION of include/sc_amd.h
 
 
 class ScError(RuntimeError):
@@ -100,7 +100,6 @@ def load() -> C.CDLL:
         "sc_initiator_step4i": (i32, [vp, i32, i32, vp, vp, i32, vp, vp, i32, i32, vp, u64]),
         "sc_keyholder_step4j_5": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, u64]),
         "sc_initiator_step67": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, u64]),
-        "sc_ctx_check": (i32, [vp, i64p]),
         "sc_rng_seed": (i32, [vp, vp]),
         "sc_rng_bits": (i32, [vp, i32, vp, u64]),
         "sc_rng_below": (i32, [vp, vp, i32, i32, vp, u64]),
@@ -113,6 +112,8 @@ def load() -> C.CDLL:
         "sc_ctx_set_onelane_mode": (i32, [vp, i32]),
         "sc_ctx_set_chip_share": (i32, [vp, i32]),
         "sc_ctx_set_fork_mode": (i32, [vp, i32]),
+        "sc_ctx_policy": (i32, [vp, C.POINTER(C.c_double)]),
+        "sc_clock_probe": (i32, [vp, i32, vp, u64, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "sc_comm_unique_id": (i32, [vp, vp]),
         "sc_comm_init": (i32, [vp, vp, i32, i32]),
         "sc_allgather": (i32, [vp, vp, vp, u64]),

@@ -6,7 +6,6 @@ SC/keyholder.py:70-133), excluding key generation, table build, host RNG and tra
 """
 from __future__ import annotations
 
-import os
 from dataclasses import dataclass
 
 import torch
@@ -15,13 +14,6 @@ from ._views import cat_rows
 from .initiator import Initiator
 from .keyholder import KeyHolder
 from .schemes import DGK, Paillier
-
-
-# The batch driver CAN read the verdicts of a step's three inversions together at its end (defer_checks=True or
-# SC_AMD_DEFER_CHECKS=1: no host round trip inside the step, SC_STEP_DEFER_CHECKS / sc_ctx_check).  Measured on one box it changes
-# nothing at B = 65536 (174.2 / 173.2 k against 174.4 / 173.9 k with two shards, 166.8 against 166.5 k on one stream) and costs 2 % at
-# B = 4096 with the second context (99.2 against 101.1 k), so the default stays one round trip per inversion.
-_DEFER = os.environ.get("SC_AMD_DEFER_CHECKS", "0") == "1"
 
 
 @dataclass
@@ -130,7 +122,7 @@ class _AheadOfTime:
 
 def secure_comparison_batch(x_enc: torch.Tensor, y_enc: torch.Tensor, l: int, alice_paillier: Paillier, alice_dgk: DGK,
                             bob_paillier: Paillier, bob_dgk: DGK, draws: BatchDraws, randomize: bool | str = True,
-                            trace: BatchTrace | None = None, side: "PartySet | None" = None, defer_checks: bool | None = None) -> torch.Tensor:
+                            trace: BatchTrace | None = None, side: "PartySet | None" = None, out: torch.Tensor | None = None) -> torch.Tensor:
     """[[x <= y]] for B comparisons.  x_enc, y_enc: [B][2nw] Paillier ciphertexts under Bob's key.
     randomize: True = every `.randomize()` of the interactive protocol, computed from the injected randomizer inputs in `draws`;
     "pool" = the same randomizations with pre-generated randomizers from the schemes' device pools (boot_pools), i.e. the
@@ -138,25 +130,23 @@ def secure_comparison_batch(x_enc: torch.Tensor, y_enc: torch.Tensor, l: int, al
     False = the static step chain without randomization.
     side: both parties' scheme objects bound to a SECOND engine and stream (same keys): with randomize=True the randomizer
     exponentiations run there, concurrently with the critical path on the caller's stream (see _AheadOfTime) -- inside this
-    call, so they are part of the step; identical results."""
+    call, so they are part of the step; identical results.
+    out: the [B][2nw] array the results are written to (e.g. a shard's row block of the whole batch's result array)."""
     if randomize == "pool":
         return _secure_comparison_batch_pooled(x_enc, y_enc, l, alice_paillier, alice_dgk, bob_paillier, bob_dgk, draws)
-    defer = _DEFER if defer_checks is None else bool(defer_checks)
     if side is not None and randomize:
         ahead = _AheadOfTime(side, draws, l)
         count = x_enc.shape[0]
-        z_enc, a_plain = Initiator.step_1_batch(x_enc, y_enc, l, alice_paillier, draws.r, None, defer_checks=defer)
+        z_enc, a_plain = Initiator.step_1_batch(x_enc, y_enc, l, alice_paillier, draws.r, None)
         z_enc = alice_paillier.add_batch(z_enc, ahead.take("rz"))
         b_plain, d_enc, beta_enc = KeyHolder.step_2_4b_batch(z_enc, l, bob_paillier, bob_dgk,
                                                              ahead.take("hr_bob").reshape(l + 1, count, -1), randomizers_ready=True)
         c_sent, c_h = Initiator.step_4_batch(d_enc, beta_enc, a_plain, draws.delta_a, alice_dgk, draws.rhos, draws.permutation,
                                              ahead.take("hr_alice").reshape(l + 1, count, -1), want_unblinded=trace is not None,
-                                             randomizers_ready=True, defer_checks=defer)
+                                             randomizers_ready=True)
         delta_b, zeta_1_enc, zeta_2_enc, delta_b_enc = KeyHolder.step_4j_5_batch(c_sent, b_plain, bob_paillier, bob_dgk, ahead.take("r3"),
                                                                                  randomizers_ready=True)
-        result = Initiator.step_6_7_batch(draws.delta_a, delta_b_enc, zeta_1_enc, zeta_2_enc, a_plain, l, alice_paillier, defer_checks=defer)
-        if defer:
-            _check_engines(alice_paillier, alice_dgk)
+        result = Initiator.step_6_7_batch(draws.delta_a, delta_b_enc, zeta_1_enc, zeta_2_enc, a_plain, l, alice_paillier, out)
         if trace is not None:
             trace.z_enc, trace.z, trace.d_enc, trace.beta_enc = z_enc, b_plain.z, d_enc, beta_enc
             trace.c_step4h, trace.c_sent, trace.delta_b = c_h, c_sent, delta_b
@@ -164,37 +154,22 @@ def secure_comparison_batch(x_enc: torch.Tensor, y_enc: torch.Tensor, l: int, al
         return result
     # five library calls per batch (include/sc_amd.h, scheme-level entry points)
     # Alice: steps 1, 3 (+ the randomization of [[z]])
-    # (defer: no host round trip inside the step -- the three inversions' verdicts are read together at the end; batch driver
-    # only: a party of the interactive protocol checks before it sends)
-    z_enc, a_plain = Initiator.step_1_batch(x_enc, y_enc, l, alice_paillier, draws.r, draws.rho_z if randomize else None, defer_checks=defer)
+    z_enc, a_plain = Initiator.step_1_batch(x_enc, y_enc, l, alice_paillier, draws.r, draws.rho_z if randomize else None)
     # Bob: steps 2, 4a, 4b (+ l + 1 randomizations)
     b_plain, d_enc, beta_enc = KeyHolder.step_2_4b_batch(z_enc, l, bob_paillier, bob_dgk, draws.r_bob_dgk if randomize else None)
     # Alice: steps 4c-4i (+ l + 1 randomizations, shuffle)
     c_sent, c_h = Initiator.step_4_batch(d_enc, beta_enc, a_plain, draws.delta_a, alice_dgk, draws.rhos, draws.permutation,
-                                         draws.r_alice_dgk if randomize else None, want_unblinded=trace is not None, defer_checks=defer)
+                                         draws.r_alice_dgk if randomize else None, want_unblinded=trace is not None)
     # Bob: steps 4j, 5 (+ 3 randomizations)
     rho3 = cat_rows([draws.rho_zeta_1, draws.rho_zeta_2, draws.rho_delta_b]) if randomize else None   # three blocks of one array: a view
     delta_b, zeta_1_enc, zeta_2_enc, delta_b_enc = KeyHolder.step_4j_5_batch(c_sent, b_plain, bob_paillier, bob_dgk, rho3)
     # Alice: steps 6, 7
-    result = Initiator.step_6_7_batch(draws.delta_a, delta_b_enc, zeta_1_enc, zeta_2_enc, a_plain, l, alice_paillier, defer_checks=defer)
-    if defer:
-        _check_engines(alice_paillier, alice_dgk)
+    result = Initiator.step_6_7_batch(draws.delta_a, delta_b_enc, zeta_1_enc, zeta_2_enc, a_plain, l, alice_paillier, out)
     if trace is not None:
         trace.z_enc, trace.z, trace.d_enc, trace.beta_enc = z_enc, b_plain.z, d_enc, beta_enc
         trace.c_step4h, trace.c_sent, trace.delta_b = c_h, c_sent, delta_b
         trace.zeta_1_enc, trace.zeta_2_enc, trace.delta_b_enc = zeta_1_enc, zeta_2_enc, delta_b_enc
     return result
-
-
-def _check_engines(*schemes) -> None:
-    """Read the deferred inversion verdicts of the engines behind `schemes` (one synchronisation each; usually one engine)."""
-    seen = []
-    for s in schemes:
-        e = s.engine
-        if all(e is not o for o in seen):
-            seen.append(e)
-            if hasattr(e, "check"):
-                e.check()
 
 
 def _secure_comparison_batch_pooled(x_enc, y_enc, l, alice_paillier, alice_dgk, bob_paillier, bob_dgk, draws: BatchDraws) -> torch.Tensor:
@@ -234,15 +209,17 @@ class PartySet:
 
 
 def split_draws(draws: BatchDraws, bounds: list[tuple[int, int]]) -> list[BatchDraws]:
-    """Contiguous per-shard copies of every random input (per-bit arrays are bit-major, so a shard is not a view)."""
+    """Contiguous per-shard copies of every random input (per-bit arrays are bit-major, so a shard is not a view).  The key
+    holder's three randomizer inputs of a shard stay the row blocks of ONE array, so that the step joins them without a copy."""
     out = []
     for a, b in bounds:
+        n = b - a
+        rho = torch.cat([draws.rho_zeta_1[a:b], draws.rho_zeta_2[a:b], draws.rho_delta_b[a:b]], dim=0)
         out.append(BatchDraws(
             r=draws.r[a:b].contiguous(), delta_a=draws.delta_a[a:b].contiguous(), rhos=draws.rhos[:, a:b].contiguous(),
             permutation=None if draws.permutation is None else draws.permutation[a:b].contiguous(),
             rho_z=draws.rho_z[a:b].contiguous(), r_bob_dgk=draws.r_bob_dgk[:, a:b].contiguous(),
-            r_alice_dgk=draws.r_alice_dgk[:, a:b].contiguous(), rho_zeta_1=draws.rho_zeta_1[a:b].contiguous(),
-            rho_zeta_2=draws.rho_zeta_2[a:b].contiguous(), rho_delta_b=draws.rho_delta_b[a:b].contiguous()))
+            r_alice_dgk=draws.r_alice_dgk[:, a:b].contiguous(), rho_zeta_1=rho[:n], rho_zeta_2=rho[n:2 * n], rho_delta_b=rho[2 * n:]))
     return out
 
 
@@ -274,23 +251,35 @@ class ConcurrentShards:
                 if hasattr(scheme.engine, "set_chip_share"):
                     scheme.engine.set_chip_share(1)
 
-    def run(self, shards: list[tuple[torch.Tensor, torch.Tensor, BatchDraws]], l: int, randomize: bool | str = True) -> list[torch.Tensor]:
-        """shards[i] = (x_enc, y_enc, draws) of shard i; returns the per-shard [[x <= y]] arrays."""
+    def run(self, shards: list[tuple[torch.Tensor, torch.Tensor, BatchDraws]], l: int, randomize: bool | str = True,
+            out: torch.Tensor | None = None) -> list[torch.Tensor] | torch.Tensor:
+        """shards[i] = (x_enc, y_enc, draws) of shard i; returns the per-shard [[x <= y]] arrays -- or, with `out` ([B][2nw], B = the
+        shards' sizes together), writes every shard's rows into its block of `out` and returns `out`: the whole batch's result in
+        one array without a concatenation pass."""
         if len(shards) != len(self.parties):
             raise ValueError("one shard per party set")
         caller = torch.cuda.current_stream()
         device = caller.device
+        blocks = [None] * len(shards)
+        if out is not None:
+            sizes = [s[0].shape[0] for s in shards]
+            if out.dim() != 2 or out.shape[0] != sum(sizes) or not out.is_contiguous():
+                raise ValueError(f"out: expected a contiguous [{sum(sizes)}][words] array")
+            start = 0
+            for i, n in enumerate(sizes):
+                blocks[i] = out[start:start + n]
+                start += n
 
-        def work(p: PartySet, shard):
+        def work(p: PartySet, shard, block):
             with torch.cuda.device(device), torch.cuda.stream(p.stream):
                 p.stream.wait_stream(caller)          # the inputs were produced on the caller's stream
                 res = secure_comparison_batch(shard[0], shard[1], l, p.alice_paillier, p.alice_dgk, p.bob_paillier, p.bob_dgk,
-                                              shard[2], randomize, side=p.side)
+                                              shard[2], randomize, side=p.side, out=block)
                 res.record_stream(caller)             # the caller consumes it on its own stream
                 return res
 
-        futures = [self._pool.submit(work, p, s) for p, s in zip(self.parties, shards)]
+        futures = [self._pool.submit(work, p, s, blk) for p, s, blk in zip(self.parties, shards, blocks)]
         results = [f.result() for f in futures]       # re-raises a shard's exception here
         for p in self.parties:
             caller.wait_stream(p.stream)
-        return results
+        return results if out is None else out

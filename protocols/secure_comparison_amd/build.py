@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "sc_lib.hip")
 OUT = os.path.join(HERE, "libsc_amd.so")
 DEPS = sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith((".hip", ".h"))) + [
-    os.path.join(HERE, "..", "..", "include", "sc_amd.h")
+    os.path.join(HERE, "..", "..", "include", "sc_amd.h"), os.path.join(HERE, "..", "..", "include", "sc_amd_dev.h")
 ]
 
 

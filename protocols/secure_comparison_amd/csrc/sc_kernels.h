@@ -69,7 +69,8 @@ __global__ void __launch_bounds__(64, (G == 1 && L == 37) ? 2 : (L == 27 ? SC_L2
         if (akind == AK_CONST) {
           a_ptr = s_c + op.w1 * SP;
         } else if (akind == AK_CONSTSEL) {   // one of two LDS constants, chosen per item by a byte flag (control flow stays uniform)
-          const uint8_t f = ((const uint8_t*)args.ext[op.w1 & 0xf].ptr)[idx];
+          const VmExt& fe = args.ext[op.w1 & 0xf];                                            // stride: BYTES between items (0 = 1; 8 = the low byte of u64 flags)
+          const uint8_t f = ((const uint8_t*)fe.ptr)[idx * (fe.stride ? fe.stride : 1u)];
           a_ptr = s_c + ((f ? (op.w2 >> 8) : op.w2) & 0xff) * SP;
         } else if (akind == AK_TBL) {
           src_limbs = my_tbl + (uint64_t)op.w1 * S * TS;
@@ -158,7 +159,10 @@ __global__ void __launch_bounds__(64, (G == 1 && L == 37) ? 2 : (L == 27 ? SC_L2
         }
         case OP_LOADW:
         case OP_ADDW: {
-          const VmExt& e = args.ext[op.w1 & 0xf];
+          // imm != 0: one of two arrays, chosen per item by bit (w1 >> 12) of the u64 flag ext (w1 >> 8) & 15: set -> ext w1 & 15,
+          // clear -> ext (w1 >> 4) & 15 (same shape; the step formulas' "a if flag else b" without a select pass over the batch)
+          const bool pick = imm && ((((const uint64_t*)args.ext[(op.w1 >> 8) & 0xf].ptr)[idx] >> ((op.w1 >> 12) & 0x3f)) & 1) == 0;
+          const VmExt& e = args.ext[(pick ? (op.w1 >> 4) : op.w1) & 0xf];
           const uint64_t flat = (uint64_t)op.w2 * args.count + idx;
           const uint32_t woff = op.w3 >> 16;
           const uint32_t nw = (op.w3 & 0xffff) ? (op.w3 & 0xffff) : e.nwords;
@@ -187,10 +191,37 @@ __global__ void __launch_bounds__(64, (G == 1 && L == 37) ? 2 : (L == 27 ? SC_L2
         }
         case OP_STOREW: {
           gp.canonical(acc);
-          if (NEG1 && imm) gp.exact_div_small(acc, args.small_c, args.small_cinv);   // c (a mod n) -> a mod n, canonical modulo n
+          if (NEG1 && (imm & 1)) gp.exact_div_small(acc, args.small_c, args.small_cinv);   // c (a mod n) -> a mod n, canonical modulo n
           const VmExt& e = args.ext[op.w1 & 0xf];
           uint64_t flat = (uint64_t)op.w2 * args.count + idx;
-          if (op.w3) flat = ((const uint64_t*)args.ext[(op.w3 - 1) & 0xf].ptr)[idx];   // scatter (the shuffle of step 4i); guarded by e.limit
+          if (op.w3 && (imm & 2)) {
+            // the step-4i shuffle from the permutation itself (SC/initiator.py:212-226, :516): ext[w3-1] = int64 [inner][planes]
+            // (stride = planes, limit = inner); item (plane j, comparison b) = j * inner + b goes to output plane k with
+            // perm[b][k] == j.  A row that is not a permutation of 0 .. planes-1 is treated as the identity, so every output row
+            // is written exactly once whatever the row holds (Initiator.permutation_is_valid tells the caller before anything is
+            // sent).  One row read per item (planes * 8 bytes, every lane of the group redundantly: a few hundred instructions
+            // against the ~250 000 of the item's products) replaces a separate launch that built a destination array.
+            const VmExt& pe = args.ext[(op.w3 - 1) & 0xf];
+            const uint64_t inner = pe.limit;
+            const uint32_t planes = pe.stride;
+            const uint64_t b = idx % inner;
+            const uint32_t jp = (uint32_t)(idx / inner);
+            const int64_t* __restrict__ prow = (const int64_t*)pe.ptr + b * planes;
+            uint64_t seen0 = 0, seen1 = 0;
+            bool ok = true;
+            uint32_t found = jp;
+#pragma unroll 4
+            for (uint32_t k = 0; k < planes; k++) {
+              const uint64_t v = (uint64_t)prow[k];
+              const bool inr = v < (uint64_t)planes;
+              const uint64_t bit = 1ull << (v & 63);
+              const uint64_t word = (v & 64) ? seen1 : seen0;
+              ok = ok && inr && !(word & bit);
+              if (inr) { if (v & 64) seen1 |= bit; else seen0 |= bit; }
+              found = (inr && (uint32_t)v == jp) ? k : found;
+            }
+            flat = ok ? (uint64_t)found * inner + b : idx;
+          } else if (op.w3) flat = ((const uint64_t*)args.ext[(op.w3 - 1) & 0xf].ptr)[idx];   // scatter to explicit rows; guarded by e.limit
           gp.store_words((uint32_t*)e.ptr + flat * e.stride, e.nwords, acc, my_a, live && flat < e.limit);
           break;
         }
@@ -241,7 +272,10 @@ __global__ void __launch_bounds__(64, (G == 1 && L == 37) ? 2 : (L == 27 ? SC_L2
           break;
         }
         case OP_ADD1: {
-          acc[0] += (gp.j == 0) ? 1u : 0u;
+          // imm != 0: add bit (w1 >> 4) & 63 of the u64 flag ext w1 & 15, inverted when w1 >> 12 is set, instead of 1
+          uint32_t one = 1u;
+          if (imm) one = (uint32_t)((((const uint64_t*)args.ext[op.w1 & 0xf].ptr)[idx] >> ((op.w1 >> 4) & 0x3f)) & 1) ^ ((op.w1 >> 12) & 1);
+          acc[0] += (gp.j == 0) ? one : 0u;
           gp.renorm(acc);
           break;
         }
@@ -274,9 +308,14 @@ __global__ void __launch_bounds__(64, (G == 1 && L == 37) ? 2 : (L == 27 ? SC_L2
 // The pair interpreter: exponentiation modulo n^2 carried out with Montgomery products modulo n only (sc_device.h,
 // "pair arithmetic").  Same launch geometry and argument block as k_vm; compiled for the L = 18 configurations.
 // ---------------------------------------------------------------------------------------------
-template <int G, int L, int WB, bool NEG1 = false>
+// STAMP: diagnostic twin (sc_clock_probe, never a timed launch): every wave records s_memtime (shader clock) and s_memrealtime
+// (constant-rate clock) at entry and exit in args.stamps[4 * blockIdx.x ..], from which the host derives the engine clock the
+// kernel actually held.
+template <int G, int L, int WB, bool NEG1 = false, bool STAMP = false>
 __global__ void __launch_bounds__(64, ((G == 16 && L > 9) ? 1 : SC_PVM_WAVES)) k_pvm(const VmArgs args) {
   using GT = Grp<G, L, WB, NEG1>;
+  uint64_t stamp_c0 = 0, stamp_r0 = 0;
+  if constexpr (STAMP) { stamp_c0 = __builtin_amdgcn_s_memtime(); stamp_r0 = __builtin_amdgcn_s_memrealtime(); }
   constexpr int S = GT::S, NG = GT::NG, SP = GT::SP, WP = GT::WP;
   __shared__ uint32_t s_a[NG * SP];            // first LDS-side operand  (x0, or y0)
   __shared__ uint32_t s_a2[G == 1 ? 1 : NG * SP];  // 2 * x0 (squarings) or y1 (products); also the word scratch of PV_LOADU
@@ -401,6 +440,13 @@ __global__ void __launch_bounds__(64, ((G == 16 && L > 9) ? 1 : SC_PVM_WAVES)) k
       }
     }
   }
+  if constexpr (STAMP) {
+    const uint64_t c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+      uint64_t* o = args.stamps + 4 * (uint64_t)blockIdx.x;
+      o[0] = stamp_c0; o[1] = stamp_r0; o[2] = c1; o[3] = r1;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -442,10 +488,12 @@ __global__ void k_plain_alice(const uint32_t* __restrict__ r, const uint32_t* __
 
 // Bob's plaintext-side values derived from z (SC/keyholder.py:196, :213, :274-282):
 //   beta = z mod 2^l, dbit = [z < (N-1)/2], zeta1 = z >> l, zeta2 = (z + N) >> l if dbit else z >> l.
+//   bits (nullable): the plaintext bits of steps 4a / 4b as bytes, bit-major [l+1][count]: plane 0 = d, plane 1 + i = bit i of beta
+//   (SC/keyholder.py:213, 230-233) -- what the g^bit selection of the DGK encryption launch reads.
 __global__ void k_plain_bob(const uint32_t* __restrict__ z, const uint32_t* __restrict__ nmod,
                             const uint32_t* __restrict__ halfn, int nw, int l, uint64_t count,
                             uint64_t* __restrict__ beta, uint64_t* __restrict__ dbit, uint32_t* __restrict__ zeta1,
-                            uint32_t* __restrict__ zeta2) {
+                            uint32_t* __restrict__ zeta2, uint8_t* __restrict__ bits) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   const uint32_t* zi = z + i * nw;
@@ -456,6 +504,10 @@ __global__ void k_plain_bob(const uint32_t* __restrict__ z, const uint32_t* __re
   for (int k = nw - 1; k >= 0 && cmp == 0; k--) cmp = (zi[k] > halfn[k]) ? 1 : ((zi[k] < halfn[k]) ? -1 : 0);
   const bool d = cmp < 0;
   dbit[i] = d ? 1ull : 0ull;
+  if (bits) {
+    bits[i] = d ? 1 : 0;
+    for (int k = 0; k < l; k++) bits[(uint64_t)(k + 1) * count + i] = (uint8_t)((zlow >> k) & 1);
+  }
   const int ws = l >> 5, bs = l & 31;
   // zeta2: first the sum z + (d ? N : 0) (nw words + a carry word), then an in-place
   // ascending funnel shift (word o only reads words >= o).

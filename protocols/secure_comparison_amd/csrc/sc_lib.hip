@@ -12,10 +12,11 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
-#include "../../../include/sc_amd.h"
+#include "../../../include/sc_amd_dev.h"
 #include "sc_kernels.h"
 #include "sc_xgcd.h"
 #include "sc_rng.h"
@@ -202,13 +203,17 @@ struct sc_ctx {
   uint32_t* scratch_aux = nullptr;
   size_t scratch_aux_bytes = 0;
   bool in_aux = false;
-  struct DeferredInv { int mod; const uint32_t* x; uint64_t count; int* d_status; uint64_t top_count; };
-  std::vector<DeferredInv> deferred;                        // inversions whose verdicts have not been read yet (sc_ctx_check)
-  int status_slot_override = -1;                            // the status buffer of a deferred inversion must outlive the call
+  // verdict words of the inversion kernel: pinned host memory the kernel writes directly (one buffer per stream of the context), so
+  // the host reads them after a stream synchronisation with no copy in between -- a device-to-host copy of a few words from pageable
+  // memory is a runtime blit kernel (__amd_rocclr_copyBuffer) that queues behind other contexts' chip-filling launches
+  int* status_host[2] = {nullptr, nullptr};
+  size_t status_cap[2] = {0, 0};
   int fork_mode = 1;                                        // sc_ctx_set_fork_mode: 0 never fork inside a call, 1 automatic
   void* scheme_keys = nullptr;                              // Paillier / DGK key objects of the scheme-level entry points (sc_schemes.h)
   bool rng_seeded = false;
   uint64_t rng_call = 0;                                    // generator calls since seeding: part of every keystream's nonce
+  uint64_t* stamps = nullptr;                               // sc_clock_probe: the next (4,18,neg1) pair launch runs its stamping twin
+  uint32_t stamp_grid = 0;                                  // ... and reports its grid size here
 };
 
 namespace {
@@ -321,8 +326,21 @@ inline bool small_enough_to_fork(const sc_ctx* ctx, const Mod& m, uint64_t count
   return (count + per_wave - 1) / per_wave <= (uint64_t)ctx->num_cu * 4 / (uint64_t)ctx->chip_share;
 }
 
-enum TmpSlot { TMP_PARK = 1, TMP_XGCD_STATUS = 2, TMP_CRT = 3, TMP_PAIR = 4, TMP_INV_MEMBERS = 5, TMP_DEFER_OUT = 6, TMP_INV_BASE = 16 /* + 2*depth, + 2*depth+1 */,
-               TMP_DEFER_STATUS = 200 /* + index of the pending inversion */ };
+enum TmpSlot { TMP_PARK = 1, TMP_CRT = 3, TMP_PAIR = 4, TMP_INV_MEMBERS = 5, TMP_INV_BASE = 16 /* + 2*depth, + 2*depth+1 */ };
+
+// `count` verdict words in pinned, device-visible host memory (grow-only, per stream of the context)
+int status_words(sc_ctx* ctx, size_t count, int** out) {
+  const int s = ctx->in_aux ? 1 : 0;
+  if (ctx->status_cap[s] < count) {
+    if (ctx->status_host[s]) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipHostFree(ctx->status_host[s])); ctx->status_host[s] = nullptr; ctx->status_cap[s] = 0; }
+    const size_t want = std::max<size_t>(count, SC_INV_TOP);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipHostMalloc((void**)&ctx->status_host[s], want * sizeof(int), hipHostMallocMapped));
+    ctx->status_cap[s] = want;
+  }
+  *out = ctx->status_host[s];
+  return SC_OK;
+}
 
 // device copy of n | (n-1)/2 as canonical words (plain-word kernels)
 int device_n_half(sc_ctx* ctx, const uint32_t* n_hptr, int nw, uint32_t** out) {
@@ -380,6 +398,9 @@ struct Builder {
   void mul_extw(int ext, uint32_t off = 0) { emit(OP_MUL, AK_EXTW, 0, ext, off); muls++; }
   void mul_extl(int ext, uint32_t off = 0) { emit(OP_MUL, AK_EXTL, 0, ext, off); muls++; }
   void loadw(int ext, uint32_t off = 0, uint32_t woff = 0, uint32_t nw = 0) { emit(OP_LOADW, 0, 0, ext, off, (woff << 16) | nw); }
+  // ext_set where bit `bit` of the item's u64 flag (ext flag_ext) is set, else ext_clear (sc_vm.h)
+  void loadw_sel(int ext_set, int ext_clear, int flag_ext, int bit) { emit(OP_LOADW, 0, 1, ext_set | (ext_clear << 4) | (flag_ext << 8) | (bit << 12)); }
+  void add_flag(int flag_ext, int bit, bool invert) { emit(OP_ADD1, 0, 1, flag_ext | (bit << 4) | ((invert ? 1 : 0) << 12)); }
   void addw(int ext, uint32_t off = 0, uint32_t woff = 0, uint32_t nw = 0) { emit(OP_ADDW, 0, 0, ext, off, (woff << 16) | nw); }
   void loadt_const(int lds_idx) { emit(OP_LOADT, AK_CONST, 0, lds_idx); }
   void loadt_tbl(uint32_t e) { touch(e); emit(OP_LOADT, AK_TBL, 0, e); }
@@ -397,7 +418,9 @@ struct Builder {
   void addt(uint32_t e) { touch(e); emit(OP_ADDT, 0, e); }
   void redc(bool times_c = false) { emit(OP_REDC, 0, times_c ? 1 : 0); redcs++; }     // times_c / over_c: leaving a modulus-multiple context (sc_vm.h)
   void storew(int ext, uint32_t off = 0, bool over_c = false) { emit(OP_STOREW, 0, over_c ? 1 : 0, ext, off); }
-  void storew_at(int ext, int ext_index, bool over_c = false) { emit(OP_STOREW, 0, over_c ? 1 : 0, ext, 0, 1 + ext_index); }   // row = ext_index[item] (u64)
+  void storew_at(int ext, int ext_index, bool over_c = false, bool by_perm = false) {   // row = ext_index[item] (u64), or from a batch of permutations (sc_vm.h)
+    emit(OP_STOREW, 0, (over_c ? 1 : 0) | (by_perm ? 2 : 0), ext, 0, 1 + ext_index);
+  }
   void storel(int ext, uint32_t off = 0) { emit(OP_STOREL, 0, 0, ext, off); }
   void storeflag(int ext, uint32_t off, int lds_const) { emit(OP_STOREFLAG, 0, 0, ext, off, lds_const); }
   void end() { emit(OP_END); }
@@ -499,15 +522,15 @@ int run_vm(sc_ctx* ctx, int mod, const Prog& p, const VmExt* exts, int next, uin
   return rc;
 }
 
-template <int G, int L, int WB = 29, bool NEG1 = false>
+template <int G, int L, int WB = 29, bool NEG1 = false, bool STAMP = false>
 int launch_pvm_cfg(sc_ctx* ctx, const VmArgs& a) {
   constexpr int NG = 64 / G;
-  const int key = 1000 + 100 * L + G + (NEG1 ? 100000 : 0);
+  const int key = 1000 + 100 * L + G + (NEG1 ? 100000 : 0) + (STAMP ? 200000 : 0);
   auto it = ctx->occ_cache.find(key);
   int occ;
   if (it == ctx->occ_cache.end()) {
     int nb = 0;
-    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_pvm<G, L, WB, NEG1>, 64, 0));
+    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_pvm<G, L, WB, NEG1, STAMP>), 64, 0));
     occ = std::max(1, std::min(nb, 16));
     ctx->occ_cache[key] = occ;
   } else {
@@ -518,7 +541,8 @@ int launch_pvm_cfg(sc_ctx* ctx, const VmArgs& a) {
   VmArgs args = a;
   int rc = ensure_scratch(ctx, (size_t)grid * NG * a.nscratch * (G * L) * 4, &args.scratch);
   if (rc) return rc;
-  hipLaunchKernelGGL((k_pvm<G, L, WB, NEG1>), dim3(grid), dim3(64), 0, ctx->stream, args);
+  if constexpr (STAMP) { args.stamps = ctx->stamps; ctx->stamp_grid = grid; }
+  hipLaunchKernelGGL((k_pvm<G, L, WB, NEG1, STAMP>), dim3(grid), dim3(64), 0, ctx->stream, args);
   HIPCHK(ctx, hipGetLastError());
   return SC_OK;
 }
@@ -542,7 +566,9 @@ int run_pvm(sc_ctx* ctx, int mod, const Prog& p, const VmExt* exts, int next, ui
   if (m.L == 18) switch (m.G) {
     case 1: return launch_pvm_cfg<1, 18>(ctx, a);
     case 2: return launch_pvm_cfg<2, 18>(ctx, a);
-    case 4: return m.n0inv == 1 ? launch_pvm_cfg<4, 18, 29, true>(ctx, a) : launch_pvm_cfg<4, 18>(ctx, a);   // n = -1 (mod 2^29): no quotient multiply
+    case 4:
+      if (m.n0inv == 1 && ctx->stamps) return launch_pvm_cfg<4, 18, 29, true, true>(ctx, a);                  // sc_clock_probe's diagnostic twin
+      return m.n0inv == 1 ? launch_pvm_cfg<4, 18, 29, true>(ctx, a) : launch_pvm_cfg<4, 18>(ctx, a);   // n = -1 (mod 2^29): no quotient multiply
     case 8: return launch_pvm_cfg<8, 18>(ctx, a);
     case 16: return launch_pvm_cfg<16, 18>(ctx, a);
   }
@@ -650,6 +676,7 @@ void sc_ctx_destroy(sc_ctx* ctx) {
   if (ctx->aux_join) (void)hipEventDestroy(ctx->aux_join);
   if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
   for (auto& kv : ctx->tmp) if (kv.second.first) (void)hipFree(kv.second.first);
+  for (int* h : ctx->status_host) if (h) (void)hipHostFree(h);
   if (ctx->switch_event) (void)hipEventDestroy(ctx->switch_event);
   if (ctx->comm) (void)sc_comm_destroy(ctx);
   if (ctx->scheme_keys) free_scheme_keys(ctx->scheme_keys);
@@ -873,7 +900,7 @@ int sc_modmul_const_sel(sc_ctx* ctx, int mod, const uint32_t* a, int cst0, int c
 static int onelane_for(sc_ctx* ctx, int mod, uint64_t count);
 
 static int modexp_shared_impl(sc_ctx* ctx, int mod, int exp, const uint32_t* x, int x_words, const uint32_t* mul_into,
-                              uint32_t* out, uint8_t* flags, uint64_t count, uint64_t* any_flags = nullptr, uint64_t inner = 0) {
+                              uint32_t* out, uint8_t* flags, uint64_t count, uint64_t* any_flags, uint64_t inner) {
   if (ctx && count == 0) return SC_OK;  // empty batch: nothing to do (pointers may be null)
   if (!valid_mod(ctx, mod) || exp < 0 || exp >= (int)ctx->exps.size() || !x || (!out && !flags && !any_flags))
     return fail(ctx, SC_ERR_ARG, "sc_modexp_shared: bad argument");
@@ -912,10 +939,10 @@ static int modexp_shared_impl(sc_ctx* ctx, int mod, int exp, const uint32_t* x, 
 }
 
 int sc_modexp_shared(sc_ctx* ctx, int mod, int exp, const uint32_t* x, int x_words, const uint32_t* mul_into, uint32_t* out, uint64_t count) {
-  return modexp_shared_impl(ctx, mod, exp, x, x_words, mul_into, out, nullptr, count);
+  return modexp_shared_impl(ctx, mod, exp, x, x_words, mul_into, out, nullptr, count, nullptr, 0);
 }
 int sc_modexp_shared_isone(sc_ctx* ctx, int mod, int exp, const uint32_t* x, int x_words, uint8_t* flags, uint64_t count) {
-  return modexp_shared_impl(ctx, mod, exp, x, x_words, nullptr, nullptr, flags, count);
+  return modexp_shared_impl(ctx, mod, exp, x, x_words, nullptr, nullptr, flags, count, nullptr, 0);
 }
 int sc_modexp_shared_isone_any(sc_ctx* ctx, int mod, int exp, const uint32_t* x, int x_words, uint64_t inner, uint64_t* any_flags,
                                uint64_t count) {
@@ -1021,12 +1048,15 @@ int sc_fixedbase_pow(sc_ctx* ctx, int fbt, const uint32_t* e, int ewords, const 
 static int neg1_vm_twin(sc_ctx* ctx, int mod, uint64_t count);
 // premul (nullable): a finished factor per item (e.g. a randomizer h^r computed ahead of time on another stream) multiplied in
 // before the store -- the alternative to the fixed-base tail (fbt / e2)
+// perm (nullable, instead of dest): int64 [count / planes][planes], one permutation per comparison of a bit-major vector
+// [planes][inner]: item (j, b) is stored at plane k with perm[b][k] == j (the step-4i shuffle inside the store)
 static int modexp_var_impl(sc_ctx* ctx, int mod, const uint32_t* x, const uint32_t* e, int ewords, int ebits, int fbt,
                            const uint32_t* e2, int e2words, const uint64_t* dest, uint32_t* out, uint64_t count,
-                           const uint32_t* premul = nullptr) {
+                           const uint32_t* premul = nullptr, const int64_t* perm = nullptr, uint32_t planes = 0) {
   if (ctx && count == 0) return SC_OK;  // empty batch: nothing to do (pointers may be null)
   if (!valid_mod(ctx, mod) || !x || !e || !out || ewords <= 0 || ebits <= 0 || ebits > 32 * ewords)
     return fail(ctx, SC_ERR_ARG, "sc_modexp_var: bad argument");
+  if (perm && (dest || planes == 0 || planes > 128 || count % planes != 0)) return fail(ctx, SC_ERR_ARG, "sc_modexp_var: bad permutation batch");
   const Fbt* f = nullptr;
   if (fbt >= 0) {
     if (fbt >= (int)ctx->fbts.size() || ctx->fbts[fbt].mod != mod || !e2 || e2words <= 0) return fail(ctx, SC_ERR_ARG, "sc_modexp_var: bad fixed-base table");
@@ -1040,7 +1070,7 @@ static int modexp_var_impl(sc_ctx* ctx, int mod, const uint32_t* x, const uint32
   const bool twin = tmod >= 0;
   const int rmod = twin ? tmod : mod;
   const Mod& m = ctx->mods[mod];        // (taken after the twin exists: creating it may move the table of moduli)
-  std::string key = "mvar:" + std::to_string(rmod) + ":" + std::to_string(ebits) + ":" + std::to_string(fbt) + (dest ? ":s" : "") + (premul ? ":p" : "");
+  std::string key = "mvar:" + std::to_string(rmod) + ":" + std::to_string(ebits) + ":" + std::to_string(fbt) + (dest ? ":s" : "") + (perm ? ":q" : "") + (premul ? ":p" : "");
   auto it = ctx->progs.find(key);
   if (it == ctx->progs.end()) {
     const int w = ebits <= 4 ? 1 : (ebits <= 12 ? 2 : 3);
@@ -1053,14 +1083,14 @@ static int modexp_var_impl(sc_ctx* ctx, int mod, const uint32_t* x, const uint32
     for (int d = nd - 2; d >= 0; d--) { for (int k = 0; k < w; k++) bd.sqr(); bd.mul_tbldig(1, d * w, w, 0); }
     if (f) for (int j = 0; j < f->nwin; j++) bd.mul_fbt(3, j * f->window, f->window, j);
     if (premul) bd.mul_extw(5); else bd.redc(twin);      // (x^e R) * premul / R = x^e premul: leaves Montgomery form by itself
-    if (dest) bd.storew_at(2, 4, twin); else bd.storew(2, 0, twin);
+    if (dest || perm) bd.storew_at(2, 4, twin, perm != nullptr); else bd.storew(2, 0, twin);
     bd.end();
     Prog p; int rc = finalize_prog(ctx, ctx->mods[rmod], bd, &p); if (rc) return rc;
     it = ctx->progs.emplace(key, p).first;
   }
   // a scattered store never leaves the output array: rows >= count are dropped by the limit of the output operand
-  VmExt ex[6] = {mk_ext(x, m.nwords, m.nwords), mk_ext(e, ewords, ewords), mk_ext(out, m.nwords, m.nwords, dest ? count : ~0ull),
-                 mk_ext(e2, e2words, e2words), mk_ext(dest, 2, 2), mk_ext(premul, m.nwords, m.nwords)};
+  VmExt ex[6] = {mk_ext(x, m.nwords, m.nwords), mk_ext(e, ewords, ewords), mk_ext(out, m.nwords, m.nwords, (dest || perm) ? count : ~0ull),
+                 mk_ext(e2, e2words, e2words), perm ? mk_ext(perm, planes, 0, count / planes) : mk_ext(dest, 2, 2), mk_ext(premul, m.nwords, m.nwords)};
   return run_vm(ctx, rmod, it->second, ex, 6, count, f ? f->d_rows : nullptr);
 }
 
@@ -1139,15 +1169,22 @@ int sc_plain_alice(sc_ctx* ctx, const uint32_t* r, const uint32_t* n_hptr, int n
   return SC_OK;
 }
 
+static int plain_bob_impl(sc_ctx* ctx, const uint32_t* z, const uint32_t* n_hptr, int nw, int l, uint64_t count, uint64_t* beta,
+                          uint64_t* dbit, uint32_t* zeta1, uint32_t* zeta2, uint8_t* bits);
 int sc_plain_bob(sc_ctx* ctx, const uint32_t* z, const uint32_t* n_hptr, int nw, int l, uint64_t count, uint64_t* beta,
                  uint64_t* dbit, uint32_t* zeta1, uint32_t* zeta2) {
+  return plain_bob_impl(ctx, z, n_hptr, nw, l, count, beta, dbit, zeta1, zeta2, nullptr);
+}
+// bits (nullable): additionally the bytes [l+1][count] of d and the bits of beta (k_plain_bob)
+static int plain_bob_impl(sc_ctx* ctx, const uint32_t* z, const uint32_t* n_hptr, int nw, int l, uint64_t count, uint64_t* beta,
+                          uint64_t* dbit, uint32_t* zeta1, uint32_t* zeta2, uint8_t* bits) {
   if (ctx && count == 0) return SC_OK;  // empty batch: nothing to do (pointers may be null)
   if (!ctx || !z || !n_hptr || nw <= 0 || l <= 0 || l > 64 || !beta || !dbit || !zeta1 || !zeta2)
     return fail(ctx, SC_ERR_ARG, "sc_plain_bob: bad argument");
   if (count == 0) return SC_OK;
   uint32_t* d_n = nullptr;
   { int rc = device_n_half(ctx, n_hptr, nw, &d_n); if (rc) return rc; }
-  hipLaunchKernelGGL(k_plain_bob, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, z, d_n, d_n + nw, nw, l, count, beta, dbit, zeta1, zeta2);
+  hipLaunchKernelGGL(k_plain_bob, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, z, d_n, d_n + nw, nw, l, count, beta, dbit, zeta1, zeta2, bits);
   HIPCHK(ctx, hipGetLastError());
   return SC_OK;
 }
@@ -1169,7 +1206,7 @@ static int modinv_rec(sc_ctx* ctx, int mod, const uint32_t* x, uint32_t* out, ui
   const uint64_t TOP = SC_INV_TOP;
   if (count <= TOP) {
     int* d_status;
-    { int rc0 = tmp_buf(ctx, ctx->status_slot_override >= 0 ? ctx->status_slot_override : TMP_XGCD_STATUS, sizeof(int) * count, (void**)&d_status); if (rc0) return rc0; }
+    { int rc0 = status_words(ctx, count, &d_status); if (rc0) return rc0; }
     uint32_t* d_nw = nullptr;
     { int rc0 = device_n_half(ctx, m.n.data(), m.nwords, &d_nw); if (rc0) return rc0; }
     int rc = launch_xgcd(ctx->stream, x, out, d_nw, m.nwords, count, d_status);
@@ -1236,15 +1273,14 @@ static int modinv_find_member(sc_ctx* ctx, const Mod& m, const InvLevel& lv, int
   while (members < lv.K && members * lv.C + (uint64_t)chunk < lv.count) members++;
   uint32_t* d_m = nullptr; int* d_status = nullptr; uint32_t* d_nw = nullptr;
   { int rc0 = tmp_buf(ctx, TMP_INV_MEMBERS, (size_t)members * m.nwords * 4 * 2, (void**)&d_m); if (rc0) return rc0; }
-  { int rc0 = tmp_buf(ctx, TMP_XGCD_STATUS, sizeof(int) * members, (void**)&d_status); if (rc0) return rc0; }
+  { int rc0 = status_words(ctx, members, &d_status); if (rc0) return rc0; }
   { int rc0 = device_n_half(ctx, m.n.data(), m.nwords, &d_nw); if (rc0) return rc0; }
   HIPCHK(ctx, hipMemcpy2DAsync(d_m, (size_t)m.nwords * 4, lv.x + (size_t)chunk * m.nwords, (size_t)lv.C * m.nwords * 4,
                                (size_t)m.nwords * 4, members, hipMemcpyDeviceToDevice, ctx->stream));
   if (launch_xgcd(ctx->stream, d_m, d_m + (size_t)members * m.nwords, d_nw, m.nwords, members, d_status) != 0)
     return fail(ctx, SC_ERR_HIP, "xgcd launch failed");
-  std::vector<int> st(members);
-  HIPCHK(ctx, hipMemcpyAsync(st.data(), d_status, sizeof(int) * members, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  const volatile int* st = d_status;                    // written by the kernel, in host memory
   for (uint64_t i = 0; i < members; i++)
     if (st[i] != 1) { *out_index = (int64_t)(i * lv.C + (uint64_t)chunk); return SC_OK; }
   return fail(ctx, SC_ERR_HIP, "sc_modinv: chunk %lld is not invertible but all of its members are", (long long)chunk);
@@ -1264,10 +1300,10 @@ int sc_modinv(sc_ctx* ctx, int mod, const uint32_t* x, uint32_t* out, uint64_t c
   InvPending pend;
   int rc = modinv_rec(ctx, mod, x, out, count, &pend, 0);
   if (rc) return rc;
-  // the one host round trip of the call: the verdicts of the top kernel, read after every launch has been queued
-  std::vector<int> st(pend.top_count);
-  HIPCHK(ctx, hipMemcpyAsync(st.data(), pend.d_status, sizeof(int) * pend.top_count, hipMemcpyDeviceToHost, ctx->stream));
+  // the one host round trip of the call: the verdicts of the top kernel (in pinned host memory, written by the kernel itself),
+  // read after every launch has been queued
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  const volatile int* st = pend.d_status;
   int64_t bad = -1;
   for (uint64_t i = 0; i < pend.top_count && bad < 0; i++) if (st[i] != 1) bad = (int64_t)i;
   if (bad < 0) return SC_OK;
@@ -1283,51 +1319,6 @@ int sc_modinv(sc_ctx* ctx, int mod, const uint32_t* x, uint32_t* out, uint64_t c
   if (bad_index) *bad_index = bad;
   ctx->last_bad_index = bad;
   return fail(ctx, SC_ERR_NOT_INVERTIBLE, "element %lld is not invertible", (long long)bad);
-}
-
-// Queue an inversion WITHOUT reading its verdicts: no host round trip in the middle of a protocol step.  The verdict words stay on
-// the device (a buffer of their own per pending inversion) until sc_ctx_check reads them all at once; a non-invertible element
-// makes the outputs garbage numbers (never an out-of-bounds access) that flow through the rest of the step and are discarded when
-// the check fails.  x must stay intact until the check (it names the bad element by running the inversion again, synchronously).
-static int modinv_deferred(sc_ctx* ctx, int mod, const uint32_t* x, uint32_t* out, uint64_t count) {
-  if (count == 0) return SC_OK;
-  if (ctx->deferred.size() >= 32) return fail(ctx, SC_ERR_ARG, "too many unchecked inversions: call sc_ctx_check");
-  InvPending pend;
-  ctx->status_slot_override = TMP_DEFER_STATUS + (int)ctx->deferred.size();
-  const int rc = modinv_rec(ctx, mod, x, out, count, &pend, 0);
-  ctx->status_slot_override = -1;
-  if (rc) return rc;
-  ctx->deferred.push_back(sc_ctx::DeferredInv{mod, x, count, pend.d_status, pend.top_count});
-  return SC_OK;
-}
-
-int sc_ctx_check(sc_ctx* ctx, int64_t* bad_index) {
-  if (!ctx) return SC_ERR_ARG;
-  if (bad_index) *bad_index = -1;
-  if (ctx->deferred.empty()) return SC_OK;
-  std::vector<sc_ctx::DeferredInv> pending;
-  pending.swap(ctx->deferred);
-  std::vector<std::vector<int>> st(pending.size());
-  for (size_t i = 0; i < pending.size(); i++) {
-    st[i].resize(pending[i].top_count);
-    HIPCHK(ctx, hipMemcpyAsync(st[i].data(), pending[i].d_status, sizeof(int) * pending[i].top_count, hipMemcpyDeviceToHost, ctx->stream));
-  }
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));          // the one host round trip of the step
-  for (size_t i = 0; i < pending.size(); i++) {
-    bool bad = false;
-    for (int v : st[i]) bad = bad || v != 1;
-    if (!bad) continue;
-    // name the element: the same inversion again, with the verdicts read at once (the operands are still there)
-    const sc_ctx::DeferredInv& d = pending[i];
-    uint32_t* scratch_out;
-    { int rc0 = tmp_buf(ctx, TMP_DEFER_OUT, (size_t)d.count * ctx->mods[d.mod].nwords * 4, (void**)&scratch_out); if (rc0) return rc0; }
-    int64_t idx = -1;
-    const int rc = sc_modinv(ctx, d.mod, d.x, scratch_out, d.count, &idx);
-    if (bad_index) *bad_index = idx;
-    if (rc == SC_ERR_NOT_INVERTIBLE) return fail(ctx, rc, "element %lld of unchecked inversion %d of this step is not invertible", (long long)idx, (int)i);
-    return rc ? rc : fail(ctx, SC_ERR_HIP, "an unchecked inversion failed but its repetition did not");
-  }
-  return SC_OK;
 }
 
 int sc_dgk_step4(sc_ctx* ctx, int mod, int cst_g, int cst_ginv, int l, const uint32_t* beta, const uint32_t* beta_inv,
@@ -1572,34 +1563,109 @@ static int neg1_vm_twin(sc_ctx* ctx, int mod, uint64_t count) {
   return (t >= 0 && ctx->mods[t].small_c != 0) ? t : -1;
 }
 
-// The one-lane twin of `mod` when this batch should run on it, else `mod` itself.  Automatic policy: the modulus fits the
-// one-lane configuration and a model of the two forms' run times in rounds of the chip's resident one-lane waves (2 per SIMD, 64
-// numbers each: 131072 numbers on 256 CUs) says the one-lane form is faster (round 2: a fixed threshold of one and a half rounds).  Measured on the MI355X (1024-bit modulus, 1024-bit exponent): 196608 numbers 19.8 ->
-// 16.6 ms, 2.1 M numbers (zero tests) 37.3 -> 33.0 ms, but 98304 numbers 9.5 -> 11.6 ms -- three quarters of a round leaves a
-// quarter of the SIMDs with one wave and nobody to hide its latencies, where the two-lane form still runs 1.5 full rounds.
+// ---- the constants of the one-lane policy, measured per device ---------------------------------------------------------------
+// Both forms run in rounds of their resident waves: 2 waves per SIMD, 64 numbers per one-lane wave and 32 per two-lane wave.  What a
+// batch costs in either form is a sum of full rounds plus one partial round, and a partial round that leaves every SIMD at most one
+// wave costs about half -- how much exactly depends on the part (issue rate of a lone wave, clocks), so it is measured, once per
+// device and process, on a fixed 1024-bit odd modulus and a 256-bit exponent (the ratios are what the policy uses; the entries are
+// milliseconds of that shape).  Round 3 had these as constants fitted on one box (0.6 / 0.27 / 0.38 of a one-lane round).
+struct OneLaneCal { bool ok = false; double one_full = 1.0, one_half = 0.5, two_full = 0.6, two_half = 0.27, two_only_half = 0.38; int simds = 0; };
+static std::mutex g_cal_mutex;
+static std::map<int, OneLaneCal> g_cal;           // by device
+
+static int modexp_shared_impl(sc_ctx* ctx, int mod, int exp, const uint32_t* x, int x_words, const uint32_t* mul_into,
+                              uint32_t* out, uint8_t* flags, uint64_t count, uint64_t* any_flags, uint64_t inner);
+
+static int onelane_calibrate(sc_ctx* ctx, OneLaneCal* out) {
+  OneLaneCal c;
+  c.simds = ctx->num_cu * 4;
+  const int nw = 32;
+  Big n(nw, 0xffffffffu); n[0] = 0xffffff61u; n[nw - 1] = 0xfffffff1u;          // any odd 1024-bit number serves Montgomery arithmetic
+  Big e(8, 0xa5c3965au); e[7] = 0x96a5c35au;                                      // 256 bits, half of them set
+  int mod = -1, exp = -1;
+  int rc = create_mod(ctx, n.data(), nw, false, &mod); if (rc) return rc;
+  rc = sc_exp_create(ctx, e.data(), (int)e.size(), &exp); if (rc) return rc;
+  const uint64_t n1 = (uint64_t)c.simds * 2 * 64, n2 = n1 / 2;                    // numbers of a full one-lane / two-lane round
+  uint32_t *x = nullptr, *y = nullptr;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMalloc((void**)&x, n1 * nw * 4));
+  HIPCHK(ctx, hipMalloc((void**)&y, n1 * nw * 4));
+  HIPCHK(ctx, hipMemsetAsync(x, 0x5a, n1 * nw * 4, ctx->stream));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIPCHK(ctx, hipEventCreate(&e0)); HIPCHK(ctx, hipEventCreate(&e1));
+  const int saved_lat = ctx->latency_mode, saved_one = ctx->onelane_mode, saved_share = ctx->chip_share;
+  const double saved_macs = ctx->mac_counter;
+  ctx->latency_mode = 0; ctx->chip_share = 1;
+  auto timed = [&](int form, uint64_t count, double* ms) -> int {
+    ctx->onelane_mode = form;                       // 0: the modulus's own two-lane configuration, 2: the one-lane twin
+    double best = 1e30;
+    for (int rep = 0; rep < 3; rep++) {             // the first repetition also loads the code
+      HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
+      int r = modexp_shared_impl(ctx, mod, exp, x, nw, nullptr, y, nullptr, count, nullptr, 0); if (r) return r;
+      HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+      HIPCHK(ctx, hipEventSynchronize(e1));
+      float t = 0; HIPCHK(ctx, hipEventElapsedTime(&t, e0, e1));
+      if (rep > 0 && t < best) best = t;
+    }
+    *ms = best;
+    return SC_OK;
+  };
+  double two_15 = 0;
+  rc = timed(2, n1, &c.one_full);
+  if (!rc) rc = timed(2, n1 / 2, &c.one_half);
+  if (!rc) rc = timed(0, n2, &c.two_full);
+  if (!rc) rc = timed(0, n2 / 2, &c.two_only_half);
+  if (!rc) rc = timed(0, n2 + n2 / 2, &two_15);
+  ctx->latency_mode = saved_lat; ctx->onelane_mode = saved_one; ctx->chip_share = saved_share; ctx->mac_counter = saved_macs;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(x); (void)hipFree(y);
+  if (rc) return rc;
+  c.two_half = std::max(0.0, two_15 - c.two_full);
+  c.ok = c.one_full > 0 && c.two_full > 0;
+  *out = c;
+  return SC_OK;
+}
+
+// the calibration of this context's device (measured by the first context that asks; a failed measurement leaves round 3's constants)
+static OneLaneCal onelane_cal(sc_ctx* ctx) {
+  std::lock_guard<std::mutex> lock(g_cal_mutex);
+  auto it = g_cal.find(ctx->device);
+  if (it != g_cal.end()) return it->second;
+  OneLaneCal c;
+  if (onelane_calibrate(ctx, &c) != SC_OK) { c = OneLaneCal(); c.simds = ctx->num_cu * 4; }
+  g_cal[ctx->device] = c;
+  return c;
+}
+
+int sc_ctx_policy(sc_ctx* ctx, double* out6) {
+  if (!ctx || !out6) return SC_ERR_ARG;
+  const OneLaneCal c = onelane_cal(ctx);
+  out6[0] = c.one_full; out6[1] = c.one_half; out6[2] = c.two_full; out6[3] = c.two_half; out6[4] = c.two_only_half; out6[5] = (double)c.simds;
+  return c.ok ? SC_OK : fail(ctx, SC_ERR_HIP, "sc_ctx_policy: the calibration launches failed (the built-in constants are in use)");
+}
+
+// The one-lane twin of `mod` when this batch should run on it, else `mod` itself.  Automatic policy: the modulus fits the one-lane
+// configuration and the model above -- full rounds plus one partial round per form, with this device's measured round times -- says
+// the one-lane form is faster.  Shape of the trade (MI355X, 1024-bit modulus and exponent, profiles/r03_onelane_policy_sweep.txt):
+// 196608 numbers 19.8 -> 16.6 ms, 2.1 M numbers (zero tests) 37.3 -> 33.0 ms, but 98304 numbers 9.5 -> 11.6 ms -- three quarters of a
+// round leaves a quarter of the SIMDs with one wave and nobody to hide its latencies, where the two-lane form still runs 1.5 rounds.
 // When several contexts work on the GPU at once (concurrent shards: sc_ctx_set_chip_share) a launch owns its share of the chip
-// only, and the idle SIMDs of an under-filled launch are taken by the other contexts' kernels: the threshold counts rounds of
-// that share (two shards of 32768 comparisons: the 98304-number launches run one-lane, +1.5 % on the whole step).
+// only, and the idle SIMDs of an under-filled launch are taken by the other contexts' kernels: rounds are counted on that share
+// (two shards of 32768 comparisons: the 98304-number launches run one-lane, +1.5 % on the whole step).
 static int onelane_for(sc_ctx* ctx, int mod, uint64_t count) {
   if (ctx->onelane_mode == 0) return mod;
   {
     const Mod& m = ctx->mods[mod];
     // the residue arrays (and the raw chunks a wide operand is read in) must fit below R = 2^(28 * 37): at most 32 words
     if (m.W == kOneLane.W || m.nbits + 8 > kOneLane.W * kOneLane.G * kOneLane.L || 32 * m.nwords > kOneLane.W * kOneLane.G * kOneLane.L) return mod;
-    if (ctx->onelane_mode == 1) {
-      // Both forms run in rounds of their resident waves on this context's share of the chip: 131072 numbers per one-lane round
-      // (2 waves x 64 numbers per SIMD), 65536 per two-lane round.  Measured run times in units of a full one-lane round (x^e mod p,
-      // 1024 bits, 11.05 ms; tools/gpu_onelane_sweep.py, profiles/r03_onelane_policy_sweep.txt): one-lane 1.0 per full round and for a
-      // last round above half, 0.5 for a last round that leaves every SIMD at most one wave; two-lane 0.6 per full round and for a last
-      // round above half, 0.27 up to half (0.38 when it is the only round).  The faster form by that model runs (round 2: one-lane
-      // from one and a half rounds, which sent e.g. 131072 numbers to the two-lane form: 13.3 instead of 11.1 ms).
-      const double share = (double)ctx->chip_share / ((double)ctx->num_cu * 4 * 2 * 64);
-      const double r1 = (double)count * share, r2 = 2.0 * r1;
-      const double f1 = r1 - std::floor(r1), f2 = r2 - std::floor(r2);
-      const double one = std::floor(r1) + (f1 <= 0.0 ? 0.0 : (f1 <= 0.5 ? 0.5 : 1.0));
-      const double two = 0.6 * std::floor(r2) + (f2 <= 0.0 ? 0.0 : (f2 <= 0.5 ? (r2 < 1.0 ? 0.38 : 0.27) : 0.6));
-      if (one >= two) return mod;
-    }
+  }
+  if (ctx->onelane_mode == 1) {
+    const OneLaneCal c = onelane_cal(ctx);          // (may register moduli: no reference into ctx->mods is held across it)
+    const double share = (double)ctx->chip_share / ((double)ctx->num_cu * 4 * 2 * 64);
+    const double r1 = (double)count * share, r2 = 2.0 * r1;
+    const double f1 = r1 - std::floor(r1), f2 = r2 - std::floor(r2);
+    const double one = c.one_full * std::floor(r1) + (f1 <= 0.0 ? 0.0 : (f1 <= 0.5 ? c.one_half : c.one_full));
+    const double two = c.two_full * std::floor(r2) + (f2 <= 0.0 ? 0.0 : (f2 <= 0.5 ? (r2 < 1.0 ? c.two_only_half : c.two_half) : c.two_full));
+    if (one >= two) return mod;
   }
   auto it = ctx->onelane_twins.find(mod);
   if (it != ctx->onelane_twins.end()) return it->second < 0 ? mod : it->second;

@@ -103,56 +103,6 @@ enum SchemeTmp { TMP_S_A = 40, TMP_S_B, TMP_S_C, TMP_S_D, TMP_S_E, TMP_S_F, TMP_
 template <typename T>
 int tmp_words(sc_ctx* ctx, int slot, uint64_t elems, T** out) { return tmp_buf(ctx, slot, (size_t)elems * sizeof(T), (void**)out); }
 
-// ---- small word kernels used by the step entry points -------------------------------------------------------------------------
-// out[i] = flags[i] ? a[i] : b[i] (rows of nwords words); byte_flags (nullable) receives (flags[i] != 0) ^ invert
-__global__ void k_select_rows(const uint64_t* __restrict__ flags, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
-                              uint32_t* __restrict__ out, int nwords, uint64_t count, uint8_t* __restrict__ byte_flags, int invert) {
-  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t i = t / (uint64_t)nwords;
-  if (i >= count) return;
-  const int w = (int)(t % (uint64_t)nwords);
-  const bool f = flags[i] != 0;
-  out[t] = f ? a[t] : b[t];
-  if (byte_flags && w == 0) byte_flags[i] = (uint8_t)((f ? 1 : 0) ^ invert);
-}
-// the scatter rows of the step-4i shuffle: blinded plane j of comparison b goes to output plane k with perm[b][k] == j, i.e.
-// dest[j * B + b] = k * B + b.  A row that is not a permutation of 0 .. planes-1 is replaced by the identity, so that EVERY entry
-// of dest is written exactly once per call and the scattered store writes every output row (no fill of either array is needed;
-// the caller learns about such rows from Initiator.permutation_is_valid before anything is sent).  planes <= 128.
-__global__ void k_perm_to_dest(const int64_t* __restrict__ perm, uint64_t* __restrict__ dest, int planes, uint64_t count) {
-  const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= count) return;
-  uint64_t seen0 = 0, seen1 = 0;
-  bool ok = true;
-  for (int k = 0; k < planes; k++) {
-    const int64_t j = perm[b * planes + k];
-    if (j < 0 || j >= planes) { ok = false; continue; }
-    uint64_t& word = (j < 64) ? seen0 : seen1;
-    const uint64_t bit = 1ull << (j & 63);
-    ok = ok && !(word & bit);
-    word |= bit;
-  }
-  for (int k = 0; k < planes; k++) {
-    const uint64_t j = ok ? (uint64_t)perm[b * planes + k] : (uint64_t)k;
-    dest[j * count + b] = (uint64_t)k * count + b;
-  }
-}
-// bits[plane][b] of the key holder's steps 4a / 4b: plane 0 = d, plane 1 + i = bit i of beta (SC/keyholder.py:213, 230-233)
-__global__ void k_bob_bits(const uint64_t* __restrict__ dbit, const uint64_t* __restrict__ beta, uint8_t* __restrict__ bits, int l, uint64_t count) {
-  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (uint64_t)(l + 1) * count) return;
-  const uint64_t plane = t / count, b = t % count;
-  bits[t] = (uint8_t)((plane == 0) ? (dbit[b] & 1) : ((beta[b] >> (plane - 1)) & 1));
-}
-// delta_B as plaintext words for the encryption of step 5
-__global__ void k_u64_to_words(const uint64_t* __restrict__ v, uint32_t* __restrict__ out, int nwords, uint64_t count) {
-  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t i = t / (uint64_t)nwords;
-  if (i >= count) return;
-  const int w = (int)(t % (uint64_t)nwords);
-  out[t] = (w == 0) ? (uint32_t)v[i] : ((w == 1) ? (uint32_t)(v[i] >> 32) : 0u);
-}
-inline unsigned blocks_for(uint64_t threads) { return (unsigned)((threads + 255) / 256); }
 
 // rho^N mod N^2 for the key holder: ((rho mod p)^(q mod p-1) mod p)^p mod p^2 per prime, recombined (identical integers)
 int paillier_crt_pow_n(sc_ctx* ctx, const PaillierKey& k, const uint32_t* rho, uint32_t* out, uint64_t count) {
@@ -253,6 +203,9 @@ int sc_paillier_key_create(sc_ctx* ctx, const uint32_t* n_hptr, int nwords, cons
   }
   keys_of(ctx)->paillier.push_back(k);
   *out_key = (int)keys_of(ctx)->paillier.size() - 1;
+  // the key holder's CRT runs its half-size exponentiations under the one-lane policy: measure that policy's constants now (once
+  // per device and process), not inside the first step
+  if (k.secret && k.crt && ctx->onelane_mode == 1 && k.hw <= 32) (void)onelane_cal(ctx);
   return SC_OK;
 }
 
@@ -388,6 +341,7 @@ int sc_dgk_key_create(sc_ctx* ctx, const uint32_t* n_hptr, const uint32_t* g_hpt
   }
   keys_of(ctx)->dgk.push_back(k);
   *out_key = (int)keys_of(ctx)->dgk.size() - 1;
+  if (secret && ctx->onelane_mode == 1 && pwords <= 32) (void)onelane_cal(ctx);      // the zero tests run under the one-lane policy
   return SC_OK;
 }
 
@@ -472,16 +426,34 @@ int sc_initiator_step1(sc_ctx* ctx, int paillier_key_id, int l, const uint32_t* 
   uint32_t *m1, *xinv, *t;
   int rc = tmp_words(ctx, TMP_S_E, count * (k.nw + 1), &m1); if (rc) return rc;
   rc = tmp_words(ctx, TMP_S_F, count * 2 * k.nw, &xinv); if (rc) return rc;
-  rc = tmp_words(ctx, TMP_S_G, count * 2 * k.nw, &t); if (rc) return rc;
   rc = sc_plain_alice(ctx, r, k.n.data(), k.nw, l, count, m1, alpha, alpha_tilde, rsmall, rshift); if (rc) return rc;
   int64_t bad = -1;
-  rc = (flags & SC_STEP_DEFER_CHECKS) ? modinv_deferred(ctx, k.mod_n2, x_enc, xinv, count) : sc_modinv(ctx, k.mod_n2, x_enc, xinv, count, &bad);
+  rc = sc_modinv(ctx, k.mod_n2, x_enc, xinv, count, &bad);
   if (rc) return rc;
-  rc = sc_modmul(ctx, k.mod_n2, y_enc, 2 * k.nw, xinv, 2 * k.nw, t, count); if (rc) return rc;                       // [[y]] [[x]]^-1
-  rc = sc_paillier_encrypt_raw(ctx, k.mod_n2, k.cst_n, m1, k.nw + 1, xinv, count); if (rc) return rc;                // [[2^l + r]]
-  if (!rho_z) return sc_modmul(ctx, k.mod_n2, t, 2 * k.nw, xinv, 2 * k.nw, z_out, count);
-  rc = sc_modmul(ctx, k.mod_n2, t, 2 * k.nw, xinv, 2 * k.nw, t, count); if (rc) return rc;
-  if (flags & SC_STEP_RANDOMIZERS_READY) return sc_modmul(ctx, k.mod_n2, t, 2 * k.nw, rho_z, 2 * k.nw, z_out, count);   // rho_z^N computed ahead
+  // one launch for the rest of step 1: [[y]] [[x]]^-1 [[2^l + r]] (SC/initiator.py:254-256), times the finished randomizer when it
+  // was computed ahead of time.  Same products as the separate modmul / encrypt launches, identical residues.
+  const bool ready = rho_z && (flags & SC_STEP_RANDOMIZERS_READY);
+  const bool fused_out = !rho_z || ready;                 // else the product goes to a temporary and .randomize() (:109) finishes
+  uint32_t* dst = z_out;
+  if (!fused_out) { rc = tmp_words(ctx, TMP_S_G, count * 2 * k.nw, &t); if (rc) return rc; dst = t; }
+  const int w2 = ctx->mods[k.mod_n2].nwords;
+  std::string key = "step1:" + std::to_string(k.mod_n2) + ":" + std::to_string(k.cst_n) + (ready ? ":r" : "");
+  auto it = ctx->progs.find(key);
+  if (it == ctx->progs.end()) {
+    Builder bd; const int cn = bd.use_const(k.cst_n);
+    bd.loadw(0); bd.mul_const(0); bd.mul_extw(1);        // [[y]] [[x]]^-1
+    bd.mul_const(0); bd.stt(0);                          // ... in Montgomery form
+    bd.loadw(2, 0, 0, k.nw + 1); bd.mul_const(cn); bd.emit(OP_ADD1);   // [[2^l + r]] = 1 + (2^l + r) N  (mod N^2)
+    bd.mul_tbl(0);
+    if (ready) { bd.mul_const(0); bd.mul_extw(4); }      // times rho_z^N
+    bd.storew(3); bd.end();
+    Prog p; rc = finalize_prog(ctx, ctx->mods[k.mod_n2], bd, &p); if (rc) return rc;
+    it = ctx->progs.emplace(key, p).first;
+  }
+  VmExt ex[5] = {mk_ext(y_enc, w2, w2), mk_ext(xinv, w2, w2), mk_ext(m1, k.nw + 1, k.nw + 1),
+                 mk_ext(dst, w2, w2), mk_ext(ready ? rho_z : nullptr, w2, w2)};
+  rc = run_vm(ctx, k.mod_n2, it->second, ex, 5, count); if (rc) return rc;
+  if (fused_out) return SC_OK;
   return sc_paillier_randomize(ctx, paillier_key_id, t, rho_z, z_out, count);                                         // .randomize() (:109)
 }
 
@@ -501,13 +473,10 @@ int sc_initiator_step4i(sc_ctx* ctx, int dgk_key_id, int l, const uint32_t* c_in
   const uint32_t* premul = ready ? r_rand : nullptr;
   if (!permutation) return modexp_var_impl(ctx, k.mod_n, c_in, rhos, rho_words, ubits, fbt, e2, r_words, nullptr, c_out, items, premul);
   if (c_in == c_out) return fail(ctx, SC_ERR_ARG, "sc_initiator_step4i: a shuffled store cannot work in place");
-  uint64_t* dest;
-  int rc = tmp_words(ctx, TMP_S_H, items, &dest); if (rc) return rc;
-  // (k_perm_to_dest writes every entry of dest -- rows that are not permutations become the identity -- so every output row is
-  // stored; no fill of either array: a runtime fill / copy kernel beside another context's chip-filling launch costs milliseconds)
-  hipLaunchKernelGGL(k_perm_to_dest, dim3(blocks_for(count)), dim3(256), 0, ctx->stream, permutation, dest, (int)planes, count);
-  HIPCHK(ctx, hipGetLastError());
-  return modexp_var_impl(ctx, k.mod_n, c_in, rhos, rho_words, ubits, fbt, e2, r_words, dest, c_out, items, premul);
+  // the store of the blinding launch finds each item's output plane in the permutation itself (OP_STOREW, sc_vm.h): rows that
+  // are not permutations act as the identity, so every output row is written; no destination array, no launch to build one
+  // (round 3's 26-us k_perm_to_dest waited up to 18 ms for a wave slot beside the other shard's chip-filling launches)
+  return modexp_var_impl(ctx, k.mod_n, c_in, rhos, rho_words, ubits, fbt, e2, r_words, nullptr, c_out, items, premul, permutation, (uint32_t)planes);
 }
 
 int sc_initiator_step4(sc_ctx* ctx, int dgk_key_id, int l, const uint32_t* d_enc, const uint32_t* beta_enc, const uint64_t* alpha,
@@ -534,7 +503,7 @@ int sc_initiator_step4(sc_ctx* ctx, int dgk_key_id, int l, const uint32_t* d_enc
     joined = j;
   }
   int64_t bad = -1;
-  rc = (flags & SC_STEP_DEFER_CHECKS) ? modinv_deferred(ctx, k.mod_n, joined, inv, items) : sc_modinv(ctx, k.mod_n, joined, inv, items, &bad);
+  rc = sc_modinv(ctx, k.mod_n, joined, inv, items, &bad);
   if (rc) return rc;
   uint32_t* c_h = c_unblinded_out;
   if (!rhos) c_h = c_out;                                    // steps 4c-4h only
@@ -554,12 +523,10 @@ int sc_keyholder_step2_4b(sc_ctx* ctx, int paillier_key_id, int dgk_key_id, int 
   if (big_bits(dk->u) <= l + 2) return fail(ctx, SC_ERR_ARG, "sc_keyholder_step2_4b: u must exceed 2^(l+2) (SC/keyholder.py:212)");
   const PaillierKey p = *pk; const DgkKey d = *dk;
   int rc = sc_paillier_decrypt(ctx, paillier_key_id, z_enc, z_out, count); if (rc) return rc;
-  rc = sc_plain_bob(ctx, z_out, p.n.data(), p.nw, l, count, beta, dbit, zeta1, zeta2); if (rc) return rc;
   const uint64_t items = ((uint64_t)l + 1) * count;
   uint8_t* bits;
   rc = tmp_words(ctx, TMP_S_I, items, &bits); if (rc) return rc;
-  hipLaunchKernelGGL(k_bob_bits, dim3(blocks_for(items)), dim3(256), 0, ctx->stream, dbit, beta, bits, l, count);
-  HIPCHK(ctx, hipGetLastError());
+  rc = plain_bob_impl(ctx, z_out, p.n.data(), p.nw, l, count, beta, dbit, zeta1, zeta2, bits); if (rc) return rc;   // + the bits of steps 4a / 4b
   if (r_rand && (flags & SC_STEP_RANDOMIZERS_READY))        // r_rand holds h^r itself: g^bit * h^r is one selected-constant product
     return sc_modmul_const_sel(ctx, d.mod_n, r_rand, -1, d.cst_g, bits, d_beta_out, items);
   if (r_rand) return dgk_randomize_impl(ctx, d, nullptr, bits, r_rand, r_words, d_beta_out, items);
@@ -588,15 +555,13 @@ int sc_keyholder_step4j_5(sc_ctx* ctx, int paillier_key_id, int dgk_key_id, int 
   const PaillierKey p = *pk;
   int rc = sc_dgk_any_zero(ctx, dgk_key_id, c_enc, l + 1, count, delta_b_out); if (rc) return rc;                  // step 4j
   // step 5: three encryptions into the row blocks of one array (no copies of zeta_1 / zeta_2 into a joined plaintext array)
-  uint32_t *db_words, *enc = out3;
-  rc = tmp_words(ctx, TMP_S_E, count * 2, &db_words); if (rc) return rc;
-  hipLaunchKernelGGL(k_u64_to_words, dim3(blocks_for(count * 2)), dim3(256), 0, ctx->stream, delta_b_out, db_words, 2, count);
-  HIPCHK(ctx, hipGetLastError());
+  // (delta_B's u64 flags are read as two-word little-endian plaintexts where they lie)
+  uint32_t* enc = out3;
   if (rho3) { rc = tmp_words(ctx, TMP_S_F, 3 * count * 2 * p.nw, &enc); if (rc) return rc; }
   const size_t blk = (size_t)count * 2 * p.nw;
   rc = sc_paillier_encrypt_raw(ctx, p.mod_n2, p.cst_n, zeta1, p.nw, enc, count); if (rc) return rc;
   rc = sc_paillier_encrypt_raw(ctx, p.mod_n2, p.cst_n, zeta2, p.nw, enc + blk, count); if (rc) return rc;
-  rc = sc_paillier_encrypt_raw(ctx, p.mod_n2, p.cst_n, db_words, 2, enc + 2 * blk, count); if (rc) return rc;
+  rc = sc_paillier_encrypt_raw(ctx, p.mod_n2, p.cst_n, (const uint32_t*)delta_b_out, 2, enc + 2 * blk, count); if (rc) return rc;
   if (!rho3) return SC_OK;                                                                                             // unrandomized
   if (flags & SC_STEP_RANDOMIZERS_READY) return sc_modmul(ctx, p.mod_n2, enc, 2 * p.nw, rho3, 2 * p.nw, out3, 3 * count);   // rho^N computed ahead
   return sc_paillier_randomize(ctx, paillier_key_id, enc, rho3, out3, 3 * count);                                    // the 3 .randomize() (:126-128)
@@ -613,28 +578,71 @@ int sc_initiator_step67(sc_ctx* ctx, int paillier_key_id, const uint64_t* delta_
   // [[x<=y]] = [[zeta]] * D * [[-(r div 2^l) - (1 - delta_A)]],  D = [[delta_B]]^-1 (delta_A = 1) or [[delta_B]] (delta_A = 0):
   // steps 6 and 7 (SC/initiator.py:529-531, 558-563) with ONE inversion pass -- [[a]] [[b]] = [[a + b]] holds exactly for
   // unrandomized g = N + 1 encryptions, so the residues equal the literal formula's
-  uint32_t *inv, *dfac, *negr, *zeta;
-  uint8_t* flip;
+  uint32_t* inv;
   int rc = tmp_words(ctx, TMP_S_E, count * w2, &inv); if (rc) return rc;
-  rc = tmp_words(ctx, TMP_S_F, count * w2, &dfac); if (rc) return rc;
-  rc = tmp_words(ctx, TMP_S_G, count * w2, &negr); if (rc) return rc;
-  rc = tmp_words(ctx, TMP_S_H, count * w2, &zeta); if (rc) return rc;
-  rc = tmp_words(ctx, TMP_S_I, count, &flip); if (rc) return rc;
   int64_t bad = -1;
-  rc = (flags & SC_STEP_DEFER_CHECKS) ? modinv_deferred(ctx, k.mod_n2, delta_b_enc, inv, count) : sc_modinv(ctx, k.mod_n2, delta_b_enc, inv, count, &bad);
+  rc = sc_modinv(ctx, k.mod_n2, delta_b_enc, inv, count, &bad);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_select_rows, dim3(blocks_for(count * w2)), dim3(256), 0, ctx->stream, delta_a, inv, delta_b_enc, dfac, w2, count, flip, 1);
-  hipLaunchKernelGGL(k_select_rows, dim3(blocks_for(count * w2)), dim3(256), 0, ctx->stream, rsmall, zeta1_enc, zeta2_enc, zeta, w2, count, (uint8_t*)nullptr, 0);
-  HIPCHK(ctx, hipGetLastError());
-  rc = sc_paillier_encrypt_raw_neg(ctx, k.mod_n2, k.cst_n, rshift, k.nw, negr, count); if (rc) return rc;           // [[-(r div 2^l)]]
-  // * [[-1]] = 1 - N where delta_A = 0 (flip = 1)
-  Big neg1 = big_fit(big_mul(k.n, k.n), (size_t)w2);
-  { Big nn = big_fit(k.n, (size_t)w2); big_sub(neg1, nn); Big one((size_t)w2, 0); one[0] = 1; big_add_inplace(neg1, one); }
-  int cst_neg1;
-  rc = reg_const(ctx, k.mod_n2, neg1, &cst_neg1); if (rc) return rc;
-  rc = sc_modmul_const_sel(ctx, k.mod_n2, negr, -1, cst_neg1, flip, negr, count); if (rc) return rc;
-  rc = sc_modmul(ctx, k.mod_n2, zeta, w2, dfac, w2, zeta, count); if (rc) return rc;
-  return sc_modmul(ctx, k.mod_n2, zeta, w2, negr, w2, out, count);
+  // one launch for the rest: the selections "zeta_1 if r < (N-1)/2 else zeta_2" and "D" are per-item operand choices of the loads,
+  // and [[-(r div 2^l)]] [[-1]]^(1 - delta_A) = 1 - (r div 2^l + 1 - delta_A) N  (mod N^2) is one encryption
+  std::string key = "step67:" + std::to_string(k.mod_n2) + ":" + std::to_string(k.cst_n);
+  auto it = ctx->progs.find(key);
+  if (it == ctx->progs.end()) {
+    Builder bd; const int cn = bd.use_const(k.cst_n);
+    bd.loadw(6, 0, 0, k.nw); bd.add_flag(5, 0, true);                      // r div 2^l + (1 - delta_A)
+    bd.mul_const(cn); bd.emit(OP_NEG); bd.emit(OP_ADD1);                   // 1 - (...) N
+    bd.mul_const(0); bd.stt(0);
+    bd.loadw_sel(0, 1, 4, 0); bd.mul_const(0); bd.stt(1);                  // [[zeta]]  (SC/initiator.py:558-560)
+    bd.loadw_sel(2, 3, 5, 0); bd.mul_const(0);                             // D: [[delta_B]]^-1 where delta_A = 1 (:529-531)
+    bd.mul_tbl(1); bd.mul_tbl(0);
+    bd.redc(); bd.storew(7); bd.end();
+    Prog p; rc = finalize_prog(ctx, ctx->mods[k.mod_n2], bd, &p); if (rc) return rc;
+    it = ctx->progs.emplace(key, p).first;
+  }
+  VmExt ex[8] = {mk_ext(zeta1_enc, w2, w2), mk_ext(zeta2_enc, w2, w2), mk_ext(inv, w2, w2), mk_ext(delta_b_enc, w2, w2),
+                 mk_ext(rsmall, 2, 2), mk_ext(delta_a, 2, 2), mk_ext(rshift, k.nw, k.nw), mk_ext(out, w2, w2)};
+  return run_vm(ctx, k.mod_n2, it->second, ex, 8, count);
+}
+
+int sc_clock_probe(sc_ctx* ctx, int paillier_key_id, const uint32_t* rho, uint64_t count, double* out_ghz, double* out_ms) {
+  const PaillierKey* kp = paillier_key(ctx, paillier_key_id);
+  if (!kp || !rho || count == 0 || !out_ghz) return fail(ctx, SC_ERR_ARG, "sc_clock_probe: bad argument");
+  const PaillierKey k = *kp;
+  if ((k.secret && k.crt) || !k.pairs || sc_mod_supports_sq(ctx, k.mod_n) != 1)
+    return fail(ctx, SC_ERR_ARG, "sc_clock_probe: needs a public Paillier key with pair arithmetic (the dominant launch)");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t max_waves = (size_t)ctx->num_cu * 16;
+  uint64_t* d_st = nullptr; uint32_t* d_out = nullptr;
+  HIPCHK(ctx, hipMalloc((void**)&d_st, max_waves * 4 * sizeof(uint64_t)));
+  if (hipMalloc((void**)&d_out, (size_t)count * 2 * k.nw * 4) != hipSuccess) { (void)hipFree(d_st); return fail(ctx, SC_ERR_HIP, "sc_clock_probe: out of memory"); }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  (void)hipMemsetAsync(d_st, 0, max_waves * 4 * sizeof(uint64_t), ctx->stream);
+  ctx->stamps = d_st; ctx->stamp_grid = 0;
+  const double saved_macs = ctx->mac_counter;
+  (void)hipEventRecord(e0, ctx->stream);
+  int rc = sc_paillier_randomize(ctx, paillier_key_id, nullptr, rho, d_out, count);
+  (void)hipEventRecord(e1, ctx->stream);
+  ctx->stamps = nullptr; ctx->mac_counter = saved_macs;
+  const uint32_t grid = ctx->stamp_grid;
+  std::vector<uint64_t> st((size_t)grid * 4);
+  if (!rc && grid == 0) rc = fail(ctx, SC_ERR_UNSUPPORTED, "sc_clock_probe: this batch did not take the (4,18) modulus-multiple pair launch");
+  if (!rc && hipMemcpyAsync(st.data(), d_st, st.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = fail(ctx, SC_ERR_HIP, "sc_clock_probe: copy failed");
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = fail(ctx, SC_ERR_HIP, "sc_clock_probe: launch failed");
+  float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d_st); (void)hipFree(d_out);
+  if (rc) return rc;
+  int rate_khz = 0;                                              // rate of s_memrealtime
+  if (hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, ctx->device) != hipSuccess || rate_khz <= 0) rate_khz = 100000;
+  double sum = 0; uint64_t used = 0;
+  for (uint32_t w = 0; w < grid; w++) {
+    const uint64_t dc = st[4 * w + 2] - st[4 * w], dr = st[4 * w + 3] - st[4 * w + 1];
+    if (dr > 0 && st[4 * w + 3] != 0) { sum += (double)dc / (double)dr; used++; }
+  }
+  if (!used) return fail(ctx, SC_ERR_HIP, "sc_clock_probe: no wave recorded its clocks");
+  *out_ghz = sum / (double)used * (double)rate_khz * 1e3 / 1e9;
+  if (out_ms) *out_ms = ms;
+  return SC_OK;
 }
 
 }  // extern "C"

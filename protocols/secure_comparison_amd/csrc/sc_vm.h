@@ -13,15 +13,18 @@ enum VmOpcode : uint32_t {
   OP_END = 0,
   OP_MUL = 1,        // ACC = mont(A, ACC)                     A given by akind
   OP_LOADW = 2,      // ACC = words  ext[w1] at (off = w2), word offset w3>>16, nwords w3&0xffff (0 = ext default)
+                     //   imm != 0: w1 = extA | extB<<4 | flag ext<<8 | bit<<12: ext A where the item's u64 flag bit is set, else ext B
   OP_ADDW = 3,       // ACC += words (same addressing as LOADW), lazy limb-wise add
   OP_LOADT = 4,      // ACC = limb-form operand given by akind (table / const / fbt / ext-limbs)
   OP_REDC = 5,       // ACC = ACC / R mod n;  imm = 1 (modulus-multiple contexts): ACC = ACC c / R mod M
   OP_STOREW = 6,     // canonical(ACC) -> words ext[w1] at off w2; w3 != 0: at the flat item index ext[w3-1][item] (u64) instead;
-                     //   imm = 1 (modulus-multiple contexts): canonical(ACC) / c exactly, i.e. the residue modulo n
+                     //   imm bit 0 (modulus-multiple contexts): canonical(ACC) / c exactly, i.e. the residue modulo n
+                     //   imm bit 1 (with w3): ext[w3-1] is a batch of permutations int64 [inner][planes] (stride = planes,
+                     //   limit = inner) and item (j, b) = j * inner + b lands in row k * inner + b with perm[b][k] == j
   OP_STOREFLAG = 7,  // (canonical(ACC) == const[w3]) -> u8 ext[w1] at off w2;  imm != 0: OR the flag into the u64 ext[w1][item mod ext.stride64]
                      //   instead (ext.limit = inner count): one flag per group of items, e.g. delta_B = OR over the l+1 zero tests
   OP_STT = 8,        // scratch[imm] = ACC
-  OP_ADD1 = 9,       // ACC += 1 (lazy)
+  OP_ADD1 = 9,       // ACC += 1 (lazy);  imm != 0: ACC += bit (w1>>4)&63 of the item's u64 flag in ext w1&15, inverted if w1>>12
   OP_SUB1 = 10,      // ACC = (ACC - 1) mod R, exact limbs
   OP_QUOT = 11,      // ACC = ACC / n exactly (ACC must be an exact multiple of n, value < R)
   OP_STOREL = 12,    // limb-form store of ACC to ext[w1] at off w2 (ext stride = S)
@@ -53,7 +56,7 @@ enum VmAKind : uint32_t {
   AK_FBT = 5,     // w1 = ext | bitpos<<4 | width<<24 ; w2 = window index ; row = fbt[(win << width) + digit]
   AK_EXTW = 6,    // w1 = ext, w2 = off : plain words operand (staged through LDS)
   AK_EXTL = 7,    // w1 = ext, w2 = off : limb-form operand in an ext array (ext stride: S, or 0 = broadcast)
-  AK_CONSTSEL = 8,  // w1 = ext (one byte per item), w2 = LDS constant index for byte 0 | index for byte != 0 << 8
+  AK_CONSTSEL = 8,  // w1 = ext (one byte per item; ext.stride = bytes between items, 0 = 1), w2 = LDS constant index for byte 0 | index for byte != 0 << 8
 };
 
 struct VmOp {
@@ -83,6 +86,7 @@ struct VmArgs {
   uint32_t nconst_extra;
   uint32_t nscratch;
   uint32_t small_c, small_cinv;   // contexts of a modulus multiple M = c n: c and c^-1 mod 2^W (OP_REDC / OP_STOREW with imm = 1)
+  uint64_t* stamps;               // clock stamps of the diagnostic twin of the pair interpreter (k_pvm<.., STAMP>), else unused
   VmExt ext[VM_MAX_EXT];
 };
 

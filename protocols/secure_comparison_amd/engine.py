@@ -612,7 +612,7 @@ class Engine:
                 raise ValueError(f"{name}: {t.numel()} items, expected {count}")
 
     def initiator_step1(self, key: PaillierKey, l: int, x_enc: torch.Tensor, y_enc: torch.Tensor, r: torch.Tensor,
-                        rho_z: torch.Tensor | None = None, ready: bool = False, defer: bool = False):
+                        rho_z: torch.Tensor | None = None, ready: bool = False):
         """(z_enc, alpha, alpha_tilde, r_small, r_shift): Initiator.step_1 / step_3 for a batch, [[z]] randomized with rho_z^N
         (`ready`: rho_z holds the finished randomizers rho_z^N mod N^2, [B][2nw], computed ahead of time)."""
         count = self._items(x_enc)
@@ -626,7 +626,7 @@ class Engine:
         alpha_t, rsmall = torch.empty_like(alpha), torch.empty_like(alpha)
         rshift = self.empty(count, nw)
         self._sync_stream()
-        rc = self.lib.sc_initiator_step1(self.ctx, key.id, int(l), self._ptr(x_enc), self._ptr(y_enc), self._ptr(r), self._ptr(rho_z), int(ready) | (2 if defer else 0),
+        rc = self.lib.sc_initiator_step1(self.ctx, key.id, int(l), self._ptr(x_enc), self._ptr(y_enc), self._ptr(r), self._ptr(rho_z), int(ready),
                                          self._ptr(z), self._ptr(alpha), self._ptr(alpha_t), self._ptr(rsmall), self._ptr(rshift), count)
         self._check(rc)
         return z, alpha, alpha_t, rsmall, rshift
@@ -650,7 +650,7 @@ class Engine:
 
     def initiator_step4(self, key: DgkKey, l: int, d_enc: torch.Tensor, beta_enc: torch.Tensor, alpha: torch.Tensor, alpha_tilde: torch.Tensor,
                         rsmall: torch.Tensor, delta_a: torch.Tensor, rhos: torch.Tensor | None = None, permutation: torch.Tensor | None = None,
-                        r_rand: torch.Tensor | None = None, want_unblinded: bool = False, ready: bool = False, defer: bool = False):
+                        r_rand: torch.Tensor | None = None, want_unblinded: bool = False, ready: bool = False):
         """(c, c after step 4h or None): Initiator.step_4c .. 4i for a batch; see sc_initiator_step4 (`ready`: r_rand holds h^r)."""
         count = self._items(d_enc)
         nw = key.mod_n.nwords
@@ -669,7 +669,7 @@ class Engine:
         rc = self.lib.sc_initiator_step4(self.ctx, key.id, int(l), self._ptr(d_enc), self._ptr(beta_enc), self._ptr(alpha), self._ptr(alpha_tilde),
                                          self._ptr(rsmall), self._ptr(delta_a), self._ptr(rhos), 0 if rhos is None else rhos.shape[-1],
                                          self._ptr(permutation), self._ptr(r_rand), 0 if r_rand is None else r_rand.shape[-1],
-                                         int(ready) | (2 if defer else 0), self._ptr(mid), self._ptr(out), count)
+                                         int(ready), self._ptr(mid), self._ptr(out), count)
         self._check(rc)
         return out, mid
 
@@ -710,29 +710,19 @@ class Engine:
         return delta_b, out
 
     def initiator_step67(self, key: PaillierKey, delta_a: torch.Tensor, delta_b_enc: torch.Tensor, zeta1_enc: torch.Tensor, zeta2_enc: torch.Tensor,
-                         rsmall: torch.Tensor, rshift: torch.Tensor, defer: bool = False) -> torch.Tensor:
+                         rsmall: torch.Tensor, rshift: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
         count = self._items(delta_b_enc)
         nw = key.mod_n.nwords
         for name, t in (("delta_b_enc", delta_b_enc), ("zeta_1_enc", zeta1_enc), ("zeta_2_enc", zeta2_enc)):
             self._arr(t, name, count, 2 * nw)
         self._arr(rshift, "r_shift", count, nw)
         self._flags(count, delta_a=delta_a, rsmall=rsmall)
-        out = self.empty(count, 2 * nw)
+        out = self._out(out, count, 2 * nw)
         self._sync_stream()
         rc = self.lib.sc_initiator_step67(self.ctx, key.id, self._ptr(delta_a), self._ptr(delta_b_enc), self._ptr(zeta1_enc), self._ptr(zeta2_enc),
-                                          self._ptr(rsmall), self._ptr(rshift), 2 if defer else 0, self._ptr(out), count)
+                                          self._ptr(rsmall), self._ptr(rshift), 0, self._ptr(out), count)
         self._check(rc)
         return out
-
-    def check(self) -> None:
-        """Read the verdicts of every inversion queued with `defer=True` since the last check (sc_ctx_check: one synchronisation);
-        raises NotInvertibleError naming the element, as the undeferred calls do."""
-        self._sync_stream()
-        bad = C.c_int64(-1)
-        rc = self.lib.sc_ctx_check(self.ctx, C.byref(bad))
-        if rc == -3:
-            raise NotInvertibleError(self.lib.sc_last_error(self.ctx).decode(), int(bad.value))
-        self._check(rc)
 
     # ------------------------------------------------------------------ device-side CSPRNG (sc_rng_*)
     def rng_seed(self, key: bytes | None = None) -> None:
@@ -778,6 +768,24 @@ class Engine:
         self._sync_stream()
         self._check(self.lib.sc_peak_probe(self.ctx, C.byref(v)))
         return v.value
+
+    def policy(self) -> dict:
+        """The measured constants of the one-lane policy on this device (sc_ctx_policy; measured once per device and process)."""
+        v = (C.c_double * 6)()
+        self._sync_stream()
+        self._check(self.lib.sc_ctx_policy(self.ctx, v))
+        names = ("one_lane_full_round_ms", "one_lane_half_round_ms", "two_lane_full_round_ms", "two_lane_later_half_round_ms", "two_lane_only_half_round_ms", "simds")
+        return dict(zip(names, list(v)))
+
+    def clock_probe(self, key: "PaillierKey", rho: torch.Tensor) -> tuple[float, float]:
+        """(engine clock in GHz held by the dominant pair launch, its duration in ms) from the stamping twin of k_pvm<4,18,neg1>
+        (sc_clock_probe): rho^N mod N^2 for rho [count][nwords] -- a diagnostic, never part of a timed region."""
+        count = self._items(rho)
+        self._arr(rho, "rho", count, key.mod_n.nwords)
+        ghz, ms = C.c_double(), C.c_double()
+        self._sync_stream()
+        self._check(self.lib.sc_clock_probe(self.ctx, key.id, self._ptr(rho), count, C.byref(ghz), C.byref(ms)))
+        return ghz.value, ms.value
 
     def set_latency_mode(self, mode: int) -> None:
         """Small-batch kernel policy (sc_ctx_set_latency_mode): 0 never, 1 automatic (default), 2 whenever available."""

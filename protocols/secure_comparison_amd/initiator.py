@@ -256,28 +256,27 @@ class Initiator:
     # ------------------------------------------------------------------ batched steps (device arrays): one library call each
     @staticmethod
     def step_1_batch(x_enc: torch.Tensor, y_enc: torch.Tensor, l: int, scheme_paillier: Paillier, r: torch.Tensor,
-                     rho_z: torch.Tensor | None = None, randomizers_ready: bool = False, defer_checks: bool = False) -> tuple[torch.Tensor, AlicePlain]:
+                     rho_z: torch.Tensor | None = None, randomizers_ready: bool = False) -> tuple[torch.Tensor, AlicePlain]:
         """B times step 1 + step 3 + the plaintext side of 4c/4e/7 (sc_initiator_step1).  x_enc, y_enc: [B][2nw]; r: [B][nw]
         (injected); rho_z: [B][nw] = the `.randomize()` of [[z]] (SC/initiator.py:109) fused in -- or, with
         `randomizers_ready`, the finished randomizers rho_z^N mod N^2 ([B][2nw]) computed ahead of time."""
         n = scheme_paillier.public_key.n
         assert (1 << (l + 2)) < n // 2
         z, alpha, alpha_tilde, r_small, r_shift = scheme_paillier.engine.initiator_step1(scheme_paillier.key, l, x_enc, y_enc, r, rho_z,
-                                                                                         randomizers_ready, defer_checks)
+                                                                                         randomizers_ready)
         return z, AlicePlain(r, alpha, alpha_tilde, r_small, r_shift)
 
     @staticmethod
     def step_4_batch(d_enc: torch.Tensor, beta_is_enc: torch.Tensor, plain: AlicePlain, delta_a: torch.Tensor, scheme_dgk: DGK,
                      rhos: torch.Tensor, permutation: torch.Tensor | None = None, randomizer_exponents: torch.Tensor | None = None,
-                     want_unblinded: bool = False, randomizers_ready: bool = False,
-                     defer_checks: bool = False) -> tuple[torch.Tensor, torch.Tensor | None]:
+                     want_unblinded: bool = False, randomizers_ready: bool = False) -> tuple[torch.Tensor, torch.Tensor | None]:
         """Steps 4c .. 4i for B comparisons in ONE library call (sc_initiator_step4): the inversion pass over [d], [beta_i], the
         fused steps 4c-4h, the blinding c_i^rho_i, the re-randomization * h^r_i (`randomizer_exponents`) and the shuffle.
         With `randomizers_ready`, `randomizer_exponents` holds the finished h^r_i ([l+1][B][nw]) instead of the exponents.
         Returns ([c_i] as sent: [l+1][B][nw], and the unblinded vector of step 4h when `want_unblinded`)."""
         l = beta_is_enc.shape[0]
         return scheme_dgk.engine.initiator_step4(scheme_dgk.key, l, d_enc, beta_is_enc, plain.alpha, plain.alpha_tilde, plain.r_small, delta_a,
-                                                 rhos, permutation, randomizer_exponents, want_unblinded, randomizers_ready, defer_checks)
+                                                 rhos, permutation, randomizer_exponents, want_unblinded, randomizers_ready)
 
     @staticmethod
     def step_4c_to_4h_batch(d_enc: torch.Tensor, beta_is_enc: torch.Tensor, plain: AlicePlain, delta_a: torch.Tensor,
@@ -326,12 +325,12 @@ class Initiator:
 
     @staticmethod
     def step_6_7_batch(delta_a: torch.Tensor, delta_b_enc: torch.Tensor, zeta_1_enc: torch.Tensor, zeta_2_enc: torch.Tensor,
-                       plain: AlicePlain, l: int, scheme_paillier: Paillier, defer_checks: bool = False) -> torch.Tensor:
+                       plain: AlicePlain, l: int, scheme_paillier: Paillier, out: torch.Tensor | None = None) -> torch.Tensor:
         """Steps 6 and 7 in one library call (sc_initiator_step67) with ONE inversion pass instead of two, yielding the same
         residues: [[x<=y]] = [[zeta]] * ([[r div 2^l]] * [[beta<alpha]])^-1 with [[beta<alpha]] = [[delta_B]] (delta_A = 1) or
         [[1]] [[delta_B]]^-1 (delta_A = 0) equals [[zeta]] * D * [[-(r div 2^l) - (1 - delta_A)]] with D = [[delta_B]]^-1
         (delta_A = 1) or [[delta_B]] (delta_A = 0), because [[a]] [[b]] = [[a + b]] holds exactly for unrandomized
-        g = N + 1 encryptions (SC/initiator.py:529-531, 558-563).  `defer_checks` (here and in step_1_batch / step_4_batch): the
-        inversion's verdict is not waited for inside the call -- engine.check() reads all pending verdicts at once."""
+        g = N + 1 encryptions (SC/initiator.py:529-531, 558-563).  `out`: write the results into this [B][2nw] array (a shard's
+        row block of the whole batch's result) instead of a new one."""
         return scheme_paillier.engine.initiator_step67(scheme_paillier.key, delta_a, delta_b_enc, zeta_1_enc, zeta_2_enc, plain.r_small,
-                                                       plain.r_shift, defer_checks)
+                                                       plain.r_shift, out)

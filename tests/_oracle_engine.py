@@ -136,10 +136,7 @@ class OracleEngine:
         planes, count, nw = c.shape
         return self.modexp_shared_isone_any(key.mod_p, c.reshape(planes * count, nw), key.sk.v_p, count)
 
-    def check(self):
-        pass
-
-    def initiator_step1(self, key, l, x_enc, y_enc, r, rho_z=None, ready=False, defer=False):
+    def initiator_step1(self, key, l, x_enc, y_enc, r, rho_z=None, ready=False):
         n, n2 = key.mod_n.n, key.mod_n2.n
         m1, alpha, alpha_t, rsmall, rshift = self.plain_alice(r, n, l)
         z = self.modmul(key.mod_n2, self.modmul(key.mod_n2, y_enc, self.modinv(key.mod_n2, x_enc)), self.paillier_encrypt(key, m1))
@@ -187,7 +184,7 @@ class OracleEngine:
         return flat.reshape(lp1, count, nw)
 
     def initiator_step4(self, key, l, d_enc, beta_enc, alpha, alpha_tilde, rsmall, delta_a, rhos=None, permutation=None, r_rand=None,
-                        want_unblinded=False, ready=False, defer=False):
+                        want_unblinded=False, ready=False):
         count, nw = d_enc.shape
         inv = self.modinv(key.mod_n, torch.cat([d_enc.reshape(1, count, nw), beta_enc]).reshape((l + 1) * count, nw))
         c_h = self.dgk_step4(key.mod_n, key.sk.g, o.mod_inv(key.sk.g, key.mod_n.n), l, beta_enc, inv[count:].reshape(l, count, nw), d_enc,
@@ -205,16 +202,20 @@ class OracleEngine:
             enc = self.modmul(pkey.mod_n2, enc, rho3) if ready else self.paillier_randomize(pkey, enc, rho3)
         return delta_b, enc
 
-    def initiator_step67(self, key, delta_a, delta_b_enc, zeta1_enc, zeta2_enc, rsmall, rshift, defer=False):
+    def initiator_step67(self, key, delta_a, delta_b_enc, zeta1_enc, zeta2_enc, rsmall, rshift, out=None):
         # the LITERAL formulas of SC/initiator.py:529-531, 558-563 (two inversions): the library's one-inversion form must equal them
         n, n2 = key.mod_n.n, key.mod_n2.n
-        out = []
+        res = []
         for da, db, z1, z2, rs, sh in zip(delta_a.tolist(), self._ints(delta_b_enc), self._ints(zeta1_enc), self._ints(zeta2_enc),
                                           rsmall.tolist(), self._ints(rshift)):
             blta = db if da else (1 + n) * o.mod_inv(db, n2) % n2
             zeta = z1 if rs else z2
-            out.append(zeta * o.mod_inv((1 + sh * n) % n2 * blta % n2, n2) % n2)
-        return self.upload(out, key.mod_n2.nwords)
+            res.append(zeta * o.mod_inv((1 + sh * n) % n2 * blta % n2, n2) % n2)
+        fresh = self.upload(res, key.mod_n2.nwords)
+        if out is None:
+            return fresh
+        out.copy_(fresh)
+        return out
 
     # ---- plumbing
     def upload(self, xs, nwords):

@@ -9,10 +9,13 @@ from protocols.secure_comparison_amd import _lib
 from protocols.secure_comparison_amd.build import build_lib
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "sc_amd.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(sc_[a-z0-9_]+)\s*\(", text)))
+def declared_symbols(headers=("sc_amd.h", "sc_amd_dev.h")):
+    names = set()
+    for h in headers:
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(sc_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_library_builds_loads_and_exports_everything():
@@ -22,9 +25,15 @@ def test_library_builds_loads_and_exports_everything():
     names = declared_symbols()
     assert len(names) >= 25
     for name in names:
-        assert hasattr(lib, name), f"{name} declared in include/sc_amd.h but not exported"
-    assert sorted(_lib.SYMBOLS) == names          # the ctypes binding covers the whole header
-    assert _lib.load().sc_abi_version() == _lib.ABI_VERSION == 3
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
+    assert sorted(_lib.SYMBOLS) == names          # the ctypes binding covers both headers
+    assert _lib.load().sc_abi_version() == _lib.ABI_VERSION == 4
+    # what a maintainer binds (sc_amd.h) holds no primitive, policy switch or probe: those are sc_amd_dev.h's
+    public = declared_symbols(("sc_amd.h",))
+    assert not [n for n in public if n.startswith(("sc_mod", "sc_exp_", "sc_const_", "sc_fbt_", "sc_ctx_set_latency", "sc_ctx_set_onelane",
+                                                   "sc_ctx_set_chip", "sc_ctx_set_fork", "sc_peak", "sc_mac", "sc_table", "sc_clock", "sc_crt", "sc_plain"))]
+    assert {"sc_initiator_step1", "sc_keyholder_step2_4b", "sc_initiator_step4", "sc_keyholder_step4j_5", "sc_initiator_step67",
+            "sc_paillier_randomize", "sc_paillier_decrypt", "sc_dgk_randomize", "sc_dgk_any_zero", "sc_rng_below", "sc_allgather"} <= set(public)
 
 
 def test_no_gpu_means_loud_failure():
@@ -56,7 +65,7 @@ def test_header_is_plain_c_and_links(tmp_path):
 
         pytest.skip("no gcc here")
     src = tmp_path / "host.c"
-    src.write_text('#include "sc_amd.h"\n#include <stdio.h>\n'
+    src.write_text('#include "sc_amd.h"\n#include "sc_amd_dev.h"\n#include <stdio.h>\n'
                    'int main(void) { printf("%d\\n", sc_abi_version()); return 0; }\n')
     exe = tmp_path / "host"
     libdir = os.path.dirname(OUT)

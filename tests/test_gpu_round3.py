@@ -278,10 +278,6 @@ def test_scheme_level_c_abi_with_ctypes_only(keys):
             assert lib.sc_initiator_step67(ctx, a_key, d_da, dbp, z1p, z2p, d_rsmall, d_rshift, 0, d_res, B) == 0, lib.sc_last_error(ctx)
             got = words_to_ints(back(d_res, B, 2 * nw))
             assert got == expect and [sk.dec_raw(v) for v in got] == [int(x <= y) for x, y in zip(xs, ys)]
-            # the same step without a host round trip inside (SC_STEP_DEFER_CHECKS = 2), verdicts read by sc_ctx_check
-            d_res2, bad = empty(B, 2 * nw), C.c_int64(-7)
-            assert lib.sc_initiator_step67(ctx, a_key, d_da, dbp, z1p, z2p, d_rsmall, d_rshift, 2, d_res2, B) == 0, lib.sc_last_error(ctx)
-            assert lib.sc_ctx_check(ctx, C.byref(bad)) == 0 and bad.value == -1 and words_to_ints(back(d_res2, B, 2 * nw)) == expect
             # the scheme objects' own operations: randomize, decrypt, encrypt bits, zero test -- one call each
             d_m = dev(ints_to_words(xs, nw))
             d_ct, d_rn, d_dec = empty(B, 2 * nw), empty(B, 2 * nw), empty(B, nw)
@@ -386,10 +382,10 @@ def test_interactive_protocol_on_device_draws_is_bit_exact_for_sampled_rows(engi
     assert engine.download(res[torch.tensor(idx, device=engine.device)]) == expect
 
 
-def test_deferred_inversion_verdicts_still_name_the_element(engine, keys):
-    """The batch driver queues a whole step without a host round trip (SC_STEP_DEFER_CHECKS) and reads the three inversions'
-    verdicts at its end: a ciphertext that has no inverse modulo N^2 is still reported as NotInvertibleError with its index, and
-    the engine works normally afterwards."""
+def test_a_step_names_the_element_that_has_no_inverse(engine, keys):
+    """A ciphertext that has no inverse modulo N^2 is reported by the step that inverts it as NotInvertibleError with its index in
+    the batch (the verdict words are written by the inversion kernel into pinned host memory and read after one stream
+    synchronisation: no copy kernel), and the engine works normally afterwards."""
     import bench
     from protocols.secure_comparison_amd.batch import secure_comparison_batch
     from protocols.secure_comparison_amd.engine import NotInvertibleError
@@ -398,16 +394,14 @@ def test_deferred_inversion_verdicts_still_name_the_element(engine, keys):
     l, B = 16, 5000            # above the inversion tree's top: several levels
     alice_p, alice_d, bob_p, bob_d = _schemes(engine, sk, dgk, 400)
     x, y, x_enc, y_enc, draws = bench.synth_inputs(engine, l, alice_p, bob_p, bob_d, B, 400, seed=4, shuffle=True)
-    good = secure_comparison_batch(x_enc, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws, defer_checks=True)
-    assert torch.equal(good, secure_comparison_batch(x_enc, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws, defer_checks=False))
+    good = secure_comparison_batch(x_enc, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws)
     poisoned = x_enc.clone()
     poisoned[3777] = engine.upload([sk.p * 12345], x_enc.shape[-1])[0]          # gcd(x, N^2) = p
-    for defer in (True, False):
+    for _ in range(2):
         with pytest.raises(NotInvertibleError) as ei:
-            secure_comparison_batch(poisoned, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws, defer_checks=defer)
+            secure_comparison_batch(poisoned, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws)
         assert ei.value.index == 3777
-    engine.check()                                                              # nothing pending any more
-    again = secure_comparison_batch(x_enc, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws, defer_checks=True)
+    again = secure_comparison_batch(x_enc, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws)
     assert torch.equal(again, good)
     dec = bob_p.decrypt_raw_batch(again)
     assert bool((dec[:, 0] == (x <= y).to(torch.int32)).all().item())

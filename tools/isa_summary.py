@@ -17,9 +17,10 @@ from collections import Counter
 
 
 def demangle(name: str) -> str:
-    m = re.match(r"_ZN2sc(\d+)(k_\w+?)ILi(\d+)ELi(\d+)ELi(\d+)E(?:Lb([01])E)?EE", name)
+    m = re.match(r"_ZN2sc(\d+)(k_\w+?)ILi(\d+)ELi(\d+)ELi(\d+)E(?:Lb([01])E)?(?:Lb([01])E)?EE", name)
     if m:
-        return f"{m.group(2)[:int(m.group(1))]}<{m.group(3)},{m.group(4)},{m.group(5)}" + (",neg1" if m.group(6) == "1" else "") + ">"
+        return (f"{m.group(2)[:int(m.group(1))]}<{m.group(3)},{m.group(4)},{m.group(5)}" + (",neg1" if m.group(6) == "1" else "") +
+                (",stamp" if m.group(7) == "1" else "") + ">")
     m = re.match(r"_ZN2sc(\d+)(k_\w+)", name)
     return m.group(2)[:int(m.group(1))] if m else name
 

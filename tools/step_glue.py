@@ -10,7 +10,7 @@ from collections import defaultdict
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-LIB = ("sc::", "k_select_rows", "k_perm_to_dest", "k_bob_bits", "k_u64_to_words")
+LIB = ("sc::",)
 is_lib = lambda n: any(t in n for t in LIB)                                             # noqa: E731
 starts = [i for i, r in enumerate(rows) if "k_plain_alice" in r["Kernel_Name"]]
 if len(starts) < 2:
