@@ -147,7 +147,7 @@ def interactive_protocol_leg(torch, eng, parties, ns, shard_inputs, x_enc, y_enc
     from protocols.secure_comparison_amd.batch import draw_alice, draw_bob
     from protocols.secure_comparison_amd.communicator import InMemoryCommunicator
 
-    def run(device_tensors: bool, sessions: int, reps: int):
+    def run(device_tensors: bool, sessions: int, reps: int, chunks: int = 1):
         inputs = [(x_enc, y_enc)] if sessions == 1 else [(si[0], si[1]) for si in shard_inputs]
         players = []
         for ps in parties[:sessions]:
@@ -163,7 +163,7 @@ def interactive_protocol_leg(torch, eng, parties, ns, shard_inputs, x_enc, y_enc
             alice, bob, ps = players[i]
 
             async def go():
-                res, _ = await asyncio.gather(alice.perform_secure_comparison_batch(*inputs[i], engine=ps.alice_paillier.engine),
+                res, _ = await asyncio.gather(alice.perform_secure_comparison_batch(*inputs[i], engine=ps.alice_paillier.engine, chunks=chunks),
                                               bob.perform_secure_comparison_batch())
                 return res
 
@@ -213,19 +213,104 @@ def interactive_protocol_leg(torch, eng, parties, ns, shard_inputs, x_enc, y_enc
     dt1, ok1, _ = run(True, 1, 2)
     dtn, okn, _ = (run(True, ns, 2) if ns > 1 else (dt1, ok1, None))
     dth, okh, st = run(False, 1, 1)
+    # the same byte transport pipelined: concurrent sessions (one session's messages drain over PCIe while the other computes) and,
+    # inside each session, the batch cut into chunks whose messages are packed on a copy stream (wire.outgoing_async)
+    piped = {}
+    for name, (sess, chunks) in (("sessions_%d" % ns, (ns, 1)), ("sessions_%d_chunks_2" % ns, (ns, 2)), ("sessions_1_chunks_4", (1, 4))):
+        if (sess, chunks) == (1, 1):
+            continue
+        dt_, ok_, _ = run(False, sess, 2, chunks)
+        piped[name] = {"value": B / dt_, "ms_per_batch": dt_ * 1e3, "ratio_to_headline": B / dt_ / (headline if headline else 1.0), "correct": ok_}
+    best = max(piped.values(), key=lambda v: v["value"]) if piped else None
     return {
         "value": B / dtn, "unit": "comparisons/s", "ratio_to_headline": B / dtn / (headline if headline else 1.0),
-        "sessions": ns, "correct": ok1 and okn and okh,
+        "sessions": ns, "correct": ok1 and okn and okh and all(v["correct"] for v in piped.values()),
         "single_session": {"value": B / dt1, "ms_per_batch": dt1 * 1e3},
         "split_ms_per_batch": {"device_rng": rng_s * 1e3, "wire_pack_unpack": 0.0, "everything_else_gpu_and_host": (dt1 - rng_s) * 1e3},
         "device_rng": {"bytes_per_comparison": rng_bytes / B, "GB_per_s": rng_bytes / rng_s / 1e9,
                        "generator": "ChaCha20 block function (RFC 8439) in counter mode, keyed per context from the OS; rejection sampling, coins and shuffles on the device"},
-        "byte_transport": {"value": B / dth, "ms_per_batch": dth * 1e3, "wire_pack_ms": st["pack_s"] * 1e3, "wire_unpack_ms": st["unpack_s"] * 1e3,
+        "byte_transport": {"value": best["value"] if best else B / dth, "ratio_to_headline": (best["value"] if best else B / dth) / (headline if headline else 1.0),
+                           "pipelined": piped,
+                           "single_session_unpipelined": {"value": B / dth, "ms_per_batch": dth * 1e3},
+                           "ms_per_batch": dth * 1e3, "wire_pack_ms": st["pack_s"] * 1e3, "wire_unpack_ms": st["unpack_s"] * 1e3,
                            "wire_bytes_per_comparison": st["bytes"] / B,
                            "note": "same protocol with every message serialized into one pinned host buffer (one device-to-host copy per array) and "
-                                   "parsed back (one host-to-device copy per array): what a transport between two processes adds"},
+                                   "parsed back (one host-to-device copy per array): what a transport between two processes adds.  value = the best "
+                                   "pipelined form (concurrent sessions and / or chunked batches with the copies on their own stream); ms_per_batch and "
+                                   "the pack / unpack split are those of ONE unpipelined session"},
         "note": "draws=None: all random inputs generated on the device inside the timed region; messages are the device arrays themselves "
                 "(InMemoryCommunicator.device_tensors); informational, never `value`"}
+
+
+def latency_single_leg(torch, eng, keys):
+    """BASELINE configs[0]: ONE comparison, x = 23, y = 42, l = 16, 1024-bit Paillier + 1024-bit DGK -- the reference's primary use
+    (SC/initiator.py:69-175, README.md:99-141).  Wall-clock milliseconds of the two players' perform_secure_comparison coroutines
+    over the in-memory transport (scheme hand-over, the 4 + 2(l+1) randomizers generated on the spot, all four exchanges), through
+    the step-level library calls on one-element batches (the default) and through the reference-shaped body that launches one
+    kernel per ciphertext operator; and of the static step chain without randomization.  There is no CPU path in the product:
+    this is what a batch of one costs on a GPU."""
+    import asyncio
+    import statistics
+
+    from protocols.secure_comparison_amd import DGK, Initiator, KeyHolder, Paillier
+    from protocols.secure_comparison_amd.batch import BatchDraws, secure_comparison_batch
+    from protocols.secure_comparison_amd.communicator import InMemoryCommunicator
+
+    pj, dj = keys["paillier_1024"], keys["dgk_1024_l16"]
+    p, q, l = int(pj["p"], 16), int(pj["q"], 16), 16
+    H = lambda name: int(dj[name], 16)  # noqa: E731
+    bob_p = Paillier(p * q, p, q, engine=eng)
+    bob_d = DGK(H("p") * H("q"), H("g"), H("h"), H("u"), dj["t"], H("p"), H("q"), H("v_p"), H("v_q"), engine=eng, randomizer_bits=400)
+
+    def once(fused: bool):
+        comm = InMemoryCommunicator()
+        alice, bob = Initiator(l, comm, "keyholder"), KeyHolder(l, comm.peer(), "initiator", bob_p, bob_d)
+        alice.fuse_steps = bob.fuse_steps = fused
+
+        async def go():
+            res, _ = await asyncio.gather(alice.perform_secure_comparison(23, 42), bob.perform_secure_comparison())
+            return res
+
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = asyncio.run(go())
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3, bob_p.decrypt(res) == 1
+
+    def median_ms(fused: bool, reps: int):
+        once(fused)                                   # programs, tables, allocator
+        runs = [once(fused) for _ in range(reps)]
+        return statistics.median(t for t, _ in runs), all(ok for _, ok in runs)
+
+    fused_ms, ok_f = median_ms(True, 7)
+    oper_ms, ok_o = median_ms(False, 3)
+    # the static step chain (README.md:117-141; no randomization) as one five-call batch of one
+    alice_p, alice_d = bob_p.public_copy(), bob_d.public_copy()
+    up = eng.upload
+    nw, ew = alice_p.mod_n.nwords, (H("u").bit_length() + 31) // 32
+    one = lambda v, w: up([v], w)  # noqa: E731
+    draws = BatchDraws(r=one(12345678901234567890 % (p * q), nw), delta_a=eng.upload_u64([1]), rhos=up([3 + i for i in range(l + 1)], ew).reshape(l + 1, 1, ew),
+                       permutation=None, rho_z=None, r_bob_dgk=None, r_alice_dgk=None, rho_zeta_1=None, rho_zeta_2=None, rho_delta_b=None)
+    x_enc, y_enc = bob_p.encrypt_raw_batch(one(23, nw)), bob_p.encrypt_raw_batch(one(42, nw))
+
+    def chain():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r_ = secure_comparison_batch(x_enc, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws, randomize=False)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3, r_
+
+    chain()
+    chain_runs = [chain() for _ in range(7)]
+    dec = eng.download(bob_p.decrypt_raw_batch(chain_runs[-1][1]))[0]
+    return {"workload": "BASELINE configs[0]: x=23, y=42, l=16, 1024-bit Paillier + 1024-bit DGK, one comparison",
+            "interactive_ms": fused_ms, "interactive_operator_path_ms": oper_ms, "static_step_chain_ms": statistics.median(t for t, _ in chain_runs),
+            "correct": bool(ok_f and ok_o and dec == 1),
+            "note": "interactive_ms: both players' perform_secure_comparison over the in-memory transport, steps as five library calls on one-element "
+                    "batches, every randomizer generated inside the call (median of 7 after a warm-up run); interactive_operator_path_ms: the same "
+                    "exchange with one launch per ciphertext operator (Initiator.fuse_steps = False), identical ciphertexts; static_step_chain_ms: "
+                    "steps 1-7 without randomization as a batch of one.  A single comparison is a chain of dependent launches on an otherwise idle "
+                    "chip: the product has no CPU path, cpu_oracle_ms (same box, one core) is the reference point"}
 
 
 def workload_name(B, l, pbits, dbits):
@@ -264,24 +349,75 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def main() -> None:
-    args = parse_args()
+class GpuRuntime:
+    """Everything bench.py's control flow asks of the device side, in one place: the MI355X through torch's HIP runtime and the
+    library's engines.  The CPU test tier drives the SAME main() / measure() with a stand-in (tests/_bench_dry_run.py: gloo instead
+    of RCCL, wall-clock events, the test-only engine) so that the N > 1 path -- rank set-up, the per-step gather into a persistent
+    array, the rank check, rank 0's line -- is exercised before the first multi-GPU run; this class is the only one the product uses."""
+
+    backend = "nccl"       # RCCL
+
+    def __init__(self, torch) -> None:
+        self.torch = torch
+
+    def check_device(self, rank: int, local_rank: int) -> None:
+        t = self.torch
+        if t.cuda.device_count() <= local_rank:
+            raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but this node shows {t.cuda.device_count()} GPU(s) (no CPU fallback)")
+        if not t.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+        t.cuda.set_device(local_rank)
+
+    def dist_device(self, local_rank: int):
+        return self.torch.device("cuda", local_rank)
+
+    def synchronize(self) -> None:
+        self.torch.cuda.synchronize()
+
+    def event(self):
+        return self.torch.cuda.Event(enable_timing=True)
+
+    def stream(self):
+        return self.torch.cuda.Stream()
+
+    def current_device(self) -> int:
+        return self.torch.cuda.current_device()
+
+    def empty_cache(self) -> None:
+        self.torch.cuda.empty_cache()
+
+    def cu_count(self, eng) -> int:
+        return self.torch.cuda.get_device_properties(eng.device).multi_processor_count
+
+    def default_engine(self):
+        from protocols.secure_comparison_amd.schemes import default_engine
+
+        return default_engine()
+
+    def new_engine(self):
+        from protocols.secure_comparison_amd.engine import Engine
+
+        return Engine()
+
+
+def main(argv=None, runtime=None, script: str | None = None) -> None:
+    """runtime / script: the CPU dry run of the test tier passes its stand-in for GpuRuntime and its own path (the ranks a
+    `--gpus N` parent starts must be the same program)."""
+    args = parse_args(argv)
     from protocols.secure_comparison_amd import launcher
 
     # ---- ranks: start them ourselves, or check the ones a launcher started.  Nothing above this line touches the GPU.
     if args.gpus < 1:
         raise SystemExit("--gpus must be at least 1")
     if args.gpus > 1 and launcher.rank_env() is None:
-        sys.exit(launcher.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+        sys.exit(launcher.spawn_ranks(script or os.path.abspath(__file__), list(sys.argv[1:] if argv is None else argv), args.gpus,
+                                      need_gpus=runtime is None))
     rank, local_rank, world = launcher.expect_world(args.gpus)
 
     import torch
 
-    if torch.cuda.device_count() <= local_rank:
-        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but this node shows {torch.cuda.device_count()} GPU(s) (no CPU fallback)")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    rt = runtime if runtime is not None else GpuRuntime(torch)
+    rt.check_device(rank, local_rank)
     dist = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist  # noqa: F811
@@ -290,9 +426,9 @@ def main() -> None:
         import datetime
 
         # a rank that never arrives must not hang the others for torch's default half hour
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+        dist.init_process_group(rt.backend, rank=rank, world_size=world, device_id=rt.dist_device(local_rank),
                                 timeout=datetime.timedelta(seconds=int(os.environ.get("SC_AMD_RENDEZVOUS_TIMEOUT_S", launcher.RENDEZVOUS_TIMEOUT_S))))
-    line = measure(args, torch, dist, rank, world, full=True)
+    line = measure(args, torch, dist, rank, world, full=True, rt=rt)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
@@ -300,7 +436,7 @@ def main() -> None:
         dist.destroy_process_group()
 
 
-def measure(args, torch, dist, rank: int, world: int, full: bool):
+def measure(args, torch, dist, rank: int, world: int, full: bool, rt=None):
     """One configuration: set-up, warm-up, the timed steps, and (rank 0) the line's content.  full: the headline run with every
     diagnostic and informational leg; otherwise a compact sub-line (value, ms per step, whole-step fraction) of another BASELINE shape
     measured by the same code path."""
@@ -308,9 +444,8 @@ def measure(args, torch, dist, rank: int, world: int, full: bool):
     from protocols.secure_comparison_amd.batch import (BatchDraws, ConcurrentShards, PartySet, boot_pools, secure_comparison_batch,
                                                        split_draws)
     from protocols.secure_comparison_amd.distributed import shard_bounds
-    from protocols.secure_comparison_amd.engine import Engine
-    from protocols.secure_comparison_amd.schemes import default_engine
 
+    rt = rt if rt is not None else GpuRuntime(torch)
     keys = json.load(open(KEYS))
     l, B = args.l, args.batch
     pj = keys[f"paillier_{args.pbits}"]
@@ -320,9 +455,8 @@ def measure(args, torch, dist, rank: int, world: int, full: bool):
     p, q = int(pj["p"], 16), int(pj["q"], 16)
     H = lambda name: int(dj[name], 16)  # noqa: E731
     use_crt = not args.no_crt
-    eng = default_engine() if full else Engine()
-    props = torch.cuda.get_device_properties(eng.device)
-    cus = props.multi_processor_count
+    eng = rt.default_engine() if full else rt.new_engine()
+    cus = rt.cu_count(eng)
     # Two concurrent shards pay once each shard's widest launches still fill the chip by themselves: a pair launch holds 16 items per
     # wave and 8 waves per CU, so 128 comparisons of 2048-bit keys per CU and shard (256 CUs: from 32768 comparisons per GPU, +1.4 %
     # there, +5 % at 65536, +7 % at the 3072-bit configs[4] share of 32768); the weight of a comparison grows with the square of the
@@ -330,8 +464,8 @@ def measure(args, torch, dist, rank: int, world: int, full: bool):
     ns = max(1, min(args.streams, B)) if args.streams > 0 else (2 if B * (args.pbits / 2048.0) ** 2 >= 128 * cus else 1)
     ns = launcher.host_threads_per_rank(world, ns)      # shard threads of all ranks together stay within the node's cores
     use_side = bool(args.side_stream) if args.side_stream >= 0 else (B <= 32 * cus)
-    engines = [eng] + [Engine() for _ in range(1, ns)]
-    side_engines = [Engine() for _ in range(ns)] if use_side else []
+    engines = [eng] + [rt.new_engine() for _ in range(1, ns)]
+    side_engines = [rt.new_engine() for _ in range(ns)] if use_side else []
     for e_ in engines + side_engines:
         e_.set_latency_mode(args.latency_mode)
         e_.set_onelane_mode(args.onelane_mode)
@@ -356,7 +490,7 @@ def measure(args, torch, dist, rank: int, world: int, full: bool):
             if i == 0:
                 build_s = alice_d.table_build_s + bob_d.table_build_s
                 table_bytes = alice_d.table_bytes() + bob_d.table_bytes()
-            sets.append(PartySet(alice_pai, alice_d, bob_p, bob_d, torch.cuda.Stream()))
+            sets.append(PartySet(alice_pai, alice_d, bob_p, bob_d, rt.stream()))
         for i, e_s in enumerate(side_engines):      # the second context of every shard: same keys, the first context's tables
             bob_p = Paillier(p * q, p, q, engine=e_s, use_crt=use_crt)
             bob_d = DGK(H("p") * H("q"), H("g"), H("h"), H("u"), dj["t"], H("p"), H("q"), H("v_p"), H("v_q"), engine=e_s,
@@ -367,7 +501,7 @@ def measure(args, torch, dist, rank: int, world: int, full: bool):
             alice_d.prepare(), bob_d.prepare()
             alice_pai = bob_p.public_copy()
             _ = bob_p.key, alice_pai.key
-            sets[i].side = PartySet(alice_pai, alice_d, bob_p, bob_d, torch.cuda.Stream())
+            sets[i].side = PartySet(alice_pai, alice_d, bob_p, bob_d, rt.stream())
         return sets, build_s, table_bytes
 
     parties, table_build_s, table_bytes = build_parties(args.fb_window)
@@ -380,7 +514,7 @@ def measure(args, torch, dist, rank: int, world: int, full: bool):
     if ns > 1:
         bounds = [shard_bounds(B, i, ns) for i in range(ns)]
         shard_inputs = [(x_enc[a:b].contiguous(), y_enc[a:b].contiguous(), d) for (a, b), d in zip(bounds, split_draws(draws, bounds))]
-        torch.cuda.synchronize()
+        rt.synchronize()
 
     # persistent result arrays: every shard writes its rows into its block of `result_buf` (no concatenation pass inside a step),
     # and the per-step all-gather fills the same `gather_buf` every time
@@ -410,17 +544,17 @@ def measure(args, torch, dist, rank: int, world: int, full: bool):
         every step: no synchronisation is added) -- the per-step spread is read from them afterwards."""
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        rt.synchronize()
         t0 = time.perf_counter()
         if marks is not None:
-            marks.append(torch.cuda.Event(enable_timing=True))
+            marks.append(rt.event())
             marks[-1].record()
         for _ in range(steps):
             r_ = gather(fn())
             if marks is not None:
-                marks.append(torch.cuda.Event(enable_timing=True))
+                marks.append(rt.event())
                 marks[-1].record()
-        torch.cuda.synchronize()
+        rt.synchronize()
         if dist is not None:
             dist.barrier()
         dt = time.perf_counter() - t0
@@ -433,15 +567,15 @@ def measure(args, torch, dist, rank: int, world: int, full: bool):
     def dominant_launch(reps=3):
         """Alice's rho^N mod N^2 for the whole batch alone on the chip (k_pvm<4,18> + the assembly launch): seconds per launch by HIP
         events on the stream the library launches on, executed multiply-adds per launch, the pure multiply-add probe's rate."""
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0, ev1 = rt.event(), rt.event()
         alice_p.randomize_batch(x_enc, draws.rho_z)
-        torch.cuda.synchronize()
+        rt.synchronize()
         before = eng.mac_counter()
         ev0.record()
         for _ in range(reps):
             alice_p.randomize_batch(x_enc, draws.rho_z)
         ev1.record()
-        torch.cuda.synchronize()
+        rt.synchronize()
         return ev0.elapsed_time(ev1) * 1e-3 / reps, (eng.mac_counter() - before) / reps, eng.peak_probe()
 
     def clock_ghz():
@@ -462,7 +596,7 @@ def measure(args, torch, dist, rank: int, world: int, full: bool):
     res = None
     for _ in range(args.warmup):
         res = gather(step())
-    torch.cuda.synchronize()
+    rt.synchronize()
     # parity spot check outside the timed region: decrypt the results on the GPU and compare with x <= y
     expect = (x <= y).to(torch.int32)
 
@@ -472,13 +606,13 @@ def measure(args, torch, dist, rank: int, world: int, full: bool):
 
     if res is not None and not all_correct(res):
         raise SystemExit("bench.py: decrypted results differ from x <= y")
-    rccl_ranks, devices = 1, [torch.cuda.current_device()]
+    rccl_ranks, devices = 1, [rt.current_device()]
     if dist is not None:   # prove the collective sees every rank, and where the ranks sit
         ones = torch.ones(1, dtype=torch.int64, device=eng.device)
         dist.all_reduce(ones)
         rccl_ranks = int(ones.item())
         ids = torch.zeros(world, dtype=torch.int64, device=eng.device)
-        dist.all_gather_into_tensor(ids, torch.tensor([torch.cuda.current_device()], dtype=torch.int64, device=eng.device))
+        dist.all_gather_into_tensor(ids, torch.tensor([rt.current_device()], dtype=torch.int64, device=eng.device))
         devices = ids.tolist()
         if rccl_ranks != world:
             raise SystemExit(f"bench.py: the all-reduce saw {rccl_ranks} ranks, expected {world}")
@@ -501,7 +635,7 @@ def measure(args, torch, dist, rank: int, world: int, full: bool):
         del parties, step, close_step
         for e_ in engines + side_engines:
             e_.close()
-        torch.cuda.empty_cache()
+        rt.empty_cache()
         return sub
     # outside the timed region: the same reassembly through the C ABI's own RCCL communicator (sc_comm_init / sc_allgather,
     # what a host without torch would call), compared with torch.distributed's gather.  Opt-in (--c-abi-gather: a second
@@ -514,7 +648,7 @@ def measure(args, torch, dist, rank: int, world: int, full: bool):
             comm_init_from_torch(eng)
             mine = res[rank * B:(rank + 1) * B].contiguous() if world > 1 else res.contiguous()
             again = eng.allgather(mine)
-            torch.cuda.synchronize()
+            rt.synchronize()
             ok_t = torch.tensor([int(torch.equal(again, res))], dtype=torch.int64, device=eng.device)
             dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
             c_abi_gather = {"equal_to_torch_gather": bool(ok_t.item()), "ranks": world}
@@ -528,18 +662,18 @@ def measure(args, torch, dist, rank: int, world: int, full: bool):
         # timed with HIP events on the stream the library launches on (torch's current stream here)
         launch_s, launch_exec_macs, peak = dominant_launch(reps=3)
         diag_after = {"launch_ms": launch_s * 1e3, "probe_peak": peak / 1e12, "clock_ghz": clock_ghz()}
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0, ev1 = rt.event(), rt.event()
         s32 = 2 * args.pbits // 32
         alg_macs = B * (args.pbits + -(-args.pbits // 5) + 30 + 1) * (2 * s32 * s32 + s32)
         alg_bytes_launch = B * (args.pbits // 8 + 2 * (2 * args.pbits // 8))      # rho in, ciphertext in, ciphertext out
         # ---- modexp/s for the two canonical shapes of SURVEY 8(d): P = Paillier randomizer, D = DGK fixed-base randomizer
         d_exps = draws.r_alice_dgk.reshape((l + 1) * B, -1)
         alice_d.randomize_batch(None, d_exps)
-        torch.cuda.synchronize()
+        rt.synchronize()
         ev0.record()
         alice_d.randomize_batch(None, d_exps)
         ev1.record()
-        torch.cuda.synchronize()
+        rt.synchronize()
         d_rate = d_exps.shape[0] / (ev0.elapsed_time(ev1) * 1e-3)
         lit = literal_macs_per_comparison(l, args.pbits, dbits, args.rbits)
         abytes = algorithmic_bytes_per_comparison(l, args.pbits, dbits, args.rbits)
@@ -611,9 +745,10 @@ def measure(args, torch, dist, rank: int, world: int, full: bool):
                     path = os.path.join(td, "sample.json")
                     export_sample(path, eng, idx, l, x_enc, y_enc, draws, res)
 
-                    def cpu_run(interp, count, procs):
-                        cp = subprocess.run([interp, os.path.join(ROOT, "oracle", "cpu_baseline.py"), KEYS, f"paillier_{args.pbits}", dname,
-                                             str(count), str(procs), str(args.rbits), path], capture_output=True, text=True, timeout=900)
+                    def cpu_run(interp, count, procs, pname=f"paillier_{args.pbits}", dgk_name=dname, sample_path=path):
+                        cp = subprocess.run([interp, os.path.join(ROOT, "oracle", "cpu_baseline.py"), KEYS, pname, dgk_name,
+                                             str(count), str(procs), str(args.rbits)] + ([sample_path] if sample_path else []),
+                                            capture_output=True, text=True, timeout=900)
                         if cp.returncode != 0:
                             raise RuntimeError(cp.stderr.strip().splitlines()[-1] if cp.stderr.strip() else "cpu baseline failed")
                         return json.loads(cp.stdout.strip().splitlines()[-1])
@@ -625,6 +760,8 @@ def measure(args, torch, dist, rank: int, world: int, full: bool):
                                                      % (cb["count"], stride, cb["arith"], cb["cores"], cb["match_gpu"], cb["count"])}
                     one = cpu_run(py, 8, 1)                       # single-core figure
                     out["cpu_baseline"]["single_core"] = {"value": one["value"], "arith": one["arith"], "sample": one["count"]}
+                    c0 = cpu_run(py, 32, 1, "paillier_1024", "dgk_1024_l16", None)      # configs[0]'s shape on one core (latency_single below)
+                    out["cpu_baseline"]["configs0_single_core_ms"] = 1e3 / c0["value"]
                     if py != sys.executable:                      # and the pure-Python-int path of the default interpreter
                         pure = cpu_run(sys.executable, 2 * cores, cores)
                         out["cpu_baseline"]["python_int"] = {"value": pure["value"], "cores": pure["cores"], "arith": pure["arith"], "sample": pure["count"]}
@@ -647,22 +784,25 @@ def measure(args, torch, dist, rank: int, world: int, full: bool):
                 close_w()
                 sens[str(w)] = {"value": B * 2 / dt_w, "table_bytes": tb_w, "table_build_s": bs_w}
                 del ps_w, step_w, close_w
-                torch.cuda.empty_cache()
+                rt.empty_cache()
             out["window_sensitivity"] = sens
             # ---- the real two-party batch protocol (reported, never `value`): Initiator / KeyHolder
             # .perform_secure_comparison_batch with draws=None over the in-memory transport -- every random input drawn on the
             # device by the library's CSPRNG inside the timed region, messages handed over as device arrays (or, second figure,
             # serialized through one pinned host buffer per message as a real transport would need)
             out["interactive_protocol"] = interactive_protocol_leg(torch, eng, parties, ns, shard_inputs, x_enc, y_enc, expect, l, B, value)
+            # ---- BASELINE configs[0]: the latency of ONE comparison through the product (no CPU path)
+            out["latency_single"] = latency_single_leg(torch, eng, keys)
+            out["latency_single"]["cpu_oracle_ms"] = out.get("cpu_baseline", {}).get("configs0_single_core_ms")
             # ---- online phase only (reported, never `value`): randomizers pre-generated into device pools (untimed), as the
             # reference pre-generates them in background workers (boot_randomness_generation, SC/initiator.py:205-210)
             gen = torch.Generator(device=eng.device)
             gen.manual_seed(1234)
             boot_pools(B, l, alice_p, alice_d, bob_p, bob_d, source="torch", generator=gen)
-            torch.cuda.synchronize()
+            rt.synchronize()
             to = time.perf_counter()
             ro = secure_comparison_batch(x_enc, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws, randomize="pool")
-            torch.cuda.synchronize()
+            rt.synchronize()
             online_s = time.perf_counter() - to
             dec_o = bob_p.decrypt_raw_batch(ro)
             out["online_phase_only"] = {"value": B / online_s, "unit": "comparisons/s", "correct": bool((dec_o[:, 0] == expect).all().item()),
@@ -672,13 +812,13 @@ def measure(args, torch, dist, rank: int, world: int, full: bool):
             host_in = [t.cpu().pin_memory() for t in (x_enc, y_enc) + tuple(getattr(draws, n_) for n_ in names)]
             host_perm = None if draws.permutation is None else draws.permutation.cpu().pin_memory()
             for _ in range(2):                                # the first pass pays for the allocator's first-time hipMallocs
-                torch.cuda.synchronize()
+                rt.synchronize()
                 tp = time.perf_counter()
                 dv = [t.to(eng.device, non_blocking=True) for t in host_in]
                 d2 = BatchDraws(permutation=None if host_perm is None else host_perm.to(eng.device, non_blocking=True),
                                 **{n_: dv[2 + i] for i, n_ in enumerate(names)})
                 r2 = secure_comparison_batch(dv[0], dv[1], l, alice_p, alice_d, bob_p, bob_d, d2, randomize=True).cpu()
-                torch.cuda.synchronize()
+                rt.synchronize()
                 pcie_s = time.perf_counter() - tp
                 del dv, d2
             out["pcie_inclusive"] = {"value": B / pcie_s, "unit": "comparisons/s", "host_bytes_per_comparison":
@@ -695,7 +835,7 @@ def measure(args, torch, dist, rank: int, world: int, full: bool):
                     setattr(a2, k_, v_)
                 a2.streams, a2.side_stream = 0, -1
                 try:
-                    others.append(measure(a2, torch, None, 0, 1, full=False))
+                    others.append(measure(a2, torch, None, 0, 1, full=False, rt=rt))
                 except Exception as exc:  # pragma: no cover
                     others.append({"workload": workload_name(kw["batch"], kw["l"], kw["pbits"], None), "error": str(exc)[:200]})
             out["other_configs"] = others

@@ -165,8 +165,11 @@ int sc_initiator_step67(sc_ctx* ctx, int paillier_key, const uint64_t* delta_a_d
  * draws per step; these entry points produce them on the device from a counter-mode generator: the ChaCha20 block function
  * (RFC 8439 2.3), keystream(call, item) = ChaCha20_block(key, counter = 0, 1, .., nonce = (item, call_lo, call_hi)) read as
  * little-endian words, `call` = number of generator calls on this context since it was seeded.  Asynchronous on the stream.
- *   sc_rng_seed:         32-byte key from the caller (reproducible tests, known-answer vectors) or, with NULL, from the OS
- *                        (getrandom); resets the call counter.  An unseeded context seeds itself from the OS on first use.
+ *   sc_rng_seed:         32-byte key from the OS (NULL: getrandom) or from the caller -- the latter for TESTS and known-answer
+ *                        vectors only: seeding resets the call counter, so the same key replays the same streams.  An unseeded
+ *                        context seeds itself from the OS on first use.  A context belongs to one host thread at a time (see the
+ *                        conventions above); the call counter is atomic all the same, so two threads that did share a context
+ *                        would never draw one (key, call) pair twice.
  *   sc_rng_bits:         out[count][ceil(bits/32)]: uniform below 2^bits (DGK randomizer exponents).
  *   sc_rng_below:        out[count][nwords]: uniform in [0, n) or, nonzero != 0, in [1, n), by rejection sampling on the device
  *                        (r below N, rho_i in [1, u), Paillier randomizer bases in [1, N)); n must fill its top word.

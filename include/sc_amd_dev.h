@@ -36,8 +36,9 @@ int sc_ctx_set_chip_share(sc_ctx* ctx, int contexts);
  * (default): automatic; 0: never (a context that already shares the GPU with another busy one, e.g. the second context that
  * computes randomizers ahead of time).  Off as well when the latency mode is 0; forced on by latency mode 2 (tests). */
 int sc_ctx_set_fork_mode(sc_ctx* ctx, int mode);
-/* The constants behind the automatic policies, measured once per device and process at the first call that needs them (about 40 ms:
- * one full and one half round of x^e mod p on the two-lane and on the one-lane kernel) instead of fitted on one box: out[0..5] =
+/* The constants behind the automatic policies, measured once per device and process when the first secret key is created (about
+ * 80 ms: full, half and one-and-a-half rounds of x^e mod p, 1024 bits, on the two-lane and on the one-lane kernel) instead of fitted
+ * on one box: out[0..5] =
  * one-lane full round, one-lane half round, two-lane full round, two-lane half round, two-lane single half round (all in ms), and
  * the number of SIMDs the rounds were counted on.  Forces the calibration if it has not happened yet. */
 int sc_ctx_policy(sc_ctx* ctx, double* out6);

@@ -209,17 +209,22 @@ class PartySet:
 
 
 def split_draws(draws: BatchDraws, bounds: list[tuple[int, int]]) -> list[BatchDraws]:
-    """Contiguous per-shard copies of every random input (per-bit arrays are bit-major, so a shard is not a view).  The key
-    holder's three randomizer inputs of a shard stay the row blocks of ONE array, so that the step joins them without a copy."""
+    """Contiguous per-shard copies of every random input (per-bit arrays are bit-major, so a shard is not a view); fields that are
+    None -- the other party's -- stay None.  The key holder's three randomizer inputs of a shard stay the row blocks of ONE array,
+    so that the step joins them without a copy."""
+    rows = lambda t, a, b: None if t is None else t[a:b].contiguous()                 # noqa: E731
+    planes = lambda t, a, b: None if t is None else t[:, a:b].contiguous()            # noqa: E731
     out = []
     for a, b in bounds:
         n = b - a
-        rho = torch.cat([draws.rho_zeta_1[a:b], draws.rho_zeta_2[a:b], draws.rho_delta_b[a:b]], dim=0)
+        z1 = z2 = db = None
+        if draws.rho_zeta_1 is not None:
+            rho = torch.cat([draws.rho_zeta_1[a:b], draws.rho_zeta_2[a:b], draws.rho_delta_b[a:b]], dim=0)
+            z1, z2, db = rho[:n], rho[n:2 * n], rho[2 * n:]
         out.append(BatchDraws(
-            r=draws.r[a:b].contiguous(), delta_a=draws.delta_a[a:b].contiguous(), rhos=draws.rhos[:, a:b].contiguous(),
-            permutation=None if draws.permutation is None else draws.permutation[a:b].contiguous(),
-            rho_z=draws.rho_z[a:b].contiguous(), r_bob_dgk=draws.r_bob_dgk[:, a:b].contiguous(),
-            r_alice_dgk=draws.r_alice_dgk[:, a:b].contiguous(), rho_zeta_1=rho[:n], rho_zeta_2=rho[n:2 * n], rho_delta_b=rho[2 * n:]))
+            r=rows(draws.r, a, b), delta_a=rows(draws.delta_a, a, b), rhos=planes(draws.rhos, a, b), permutation=rows(draws.permutation, a, b),
+            rho_z=rows(draws.rho_z, a, b), r_bob_dgk=planes(draws.r_bob_dgk, a, b), r_alice_dgk=planes(draws.r_alice_dgk, a, b),
+            rho_zeta_1=z1, rho_zeta_2=z2, rho_delta_b=db))
     return out
 
 

@@ -5,6 +5,7 @@
 #include <sys/random.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -211,7 +212,9 @@ struct sc_ctx {
   int fork_mode = 1;                                        // sc_ctx_set_fork_mode: 0 never fork inside a call, 1 automatic
   void* scheme_keys = nullptr;                              // Paillier / DGK key objects of the scheme-level entry points (sc_schemes.h)
   bool rng_seeded = false;
-  uint64_t rng_call = 0;                                    // generator calls since seeding: part of every keystream's nonce
+  std::atomic<uint64_t> rng_call{0};                        // generator calls since seeding: part of every keystream's nonce (atomic: two
+                                                            // host threads that ever share a context must never draw one (key, call) twice)
+  std::mutex rng_seed_mutex;                                // the lazy first seeding happens once
   uint64_t* stamps = nullptr;                               // sc_clock_probe: the next (4,18,neg1) pair launch runs its stamping twin
   uint32_t stamp_grid = 0;                                  // ... and reports its grid size here
 };
@@ -1567,8 +1570,10 @@ static int neg1_vm_twin(sc_ctx* ctx, int mod, uint64_t count) {
 // Both forms run in rounds of their resident waves: 2 waves per SIMD, 64 numbers per one-lane wave and 32 per two-lane wave.  What a
 // batch costs in either form is a sum of full rounds plus one partial round, and a partial round that leaves every SIMD at most one
 // wave costs about half -- how much exactly depends on the part (issue rate of a lone wave, clocks), so it is measured, once per
-// device and process, on a fixed 1024-bit odd modulus and a 256-bit exponent (the ratios are what the policy uses; the entries are
-// milliseconds of that shape).  Round 3 had these as constants fitted on one box (0.6 / 0.27 / 0.38 of a one-lane round).
+// device and process, on a fixed 1024-bit odd modulus and a 1024-bit exponent -- the shape of the key holder's first CRT stage; a
+// 256-bit exponent gave other RATIOS (two-lane round 0.53 instead of 0.60 of a one-lane round: the window tables weigh differently)
+// and mis-ranked the forms at half a round.  About 80 ms of launches.  Round 3 had these as constants fitted on one box (0.6 / 0.27 /
+// 0.38 of a one-lane round).
 struct OneLaneCal { bool ok = false; double one_full = 1.0, one_half = 0.5, two_full = 0.6, two_half = 0.27, two_only_half = 0.38; int simds = 0; };
 static std::mutex g_cal_mutex;
 static std::map<int, OneLaneCal> g_cal;           // by device
@@ -1581,7 +1586,7 @@ static int onelane_calibrate(sc_ctx* ctx, OneLaneCal* out) {
   c.simds = ctx->num_cu * 4;
   const int nw = 32;
   Big n(nw, 0xffffffffu); n[0] = 0xffffff61u; n[nw - 1] = 0xfffffff1u;          // any odd 1024-bit number serves Montgomery arithmetic
-  Big e(8, 0xa5c3965au); e[7] = 0x96a5c35au;                                      // 256 bits, half of them set
+  Big e(32, 0xa5c3965au); e[31] = 0x96a5c35au;                                    // 1024 bits, half of them set
   int mod = -1, exp = -1;
   int rc = create_mod(ctx, n.data(), nw, false, &mod); if (rc) return rc;
   rc = sc_exp_create(ctx, e.data(), (int)e.size(), &exp); if (rc) return rc;
@@ -1599,19 +1604,21 @@ static int onelane_calibrate(sc_ctx* ctx, OneLaneCal* out) {
   auto timed = [&](int form, uint64_t count, double* ms) -> int {
     ctx->onelane_mode = form;                       // 0: the modulus's own two-lane configuration, 2: the one-lane twin
     double best = 1e30;
-    for (int rep = 0; rep < 3; rep++) {             // the first repetition also loads the code
+    for (int rep = 0; rep < 2; rep++) {
       HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
       int r = modexp_shared_impl(ctx, mod, exp, x, nw, nullptr, y, nullptr, count, nullptr, 0); if (r) return r;
       HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
       HIPCHK(ctx, hipEventSynchronize(e1));
       float t = 0; HIPCHK(ctx, hipEventElapsedTime(&t, e0, e1));
-      if (rep > 0 && t < best) best = t;
+      if (t < best) best = t;
     }
     *ms = best;
     return SC_OK;
   };
-  double two_15 = 0;
-  rc = timed(2, n1, &c.one_full);
+  double two_15 = 0, warm = 0;
+  rc = timed(2, 64, &warm);                         // program build, code load
+  if (!rc) rc = timed(0, 64, &warm);
+  if (!rc) rc = timed(2, n1, &c.one_full);
   if (!rc) rc = timed(2, n1 / 2, &c.one_half);
   if (!rc) rc = timed(0, n2, &c.two_full);
   if (!rc) rc = timed(0, n2 / 2, &c.two_only_half);
@@ -1927,9 +1934,12 @@ static int rng_begin(sc_ctx* ctx, uint64_t count, const void* out, const char* w
   if (!ctx) return SC_ERR_ARG;
   if (!out) return fail(ctx, SC_ERR_ARG, "%s: no output array", who);
   if (count > 0xffffffffull) return fail(ctx, SC_ERR_ARG, "%s: at most 2^32 - 1 items per call", who);
-  if (!ctx->rng_seeded) { int rc = sc_rng_seed(ctx, nullptr); if (rc) return rc; }
+  {
+    std::lock_guard<std::mutex> lock(ctx->rng_seed_mutex);
+    if (!ctx->rng_seeded) { int rc = sc_rng_seed(ctx, nullptr); if (rc) return rc; }
+  }
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  *call = ctx->rng_call++;
+  *call = ctx->rng_call.fetch_add(1);
   return SC_OK;
 }
 

@@ -18,6 +18,17 @@ bool big_is_zero(const Big& a) { for (uint32_t w : a) if (w) return false; retur
 bool big_is_one(const Big& a) { if (a.empty() || a[0] != 1) return false; for (size_t i = 1; i < a.size(); i++) if (a[i]) return false; return true; }
 Big big_mod(const Big& x, const Big& m) { Big q, r; big_divmod(x, m, &q, &r); return r; }       // m.size() words
 Big big_mulmod(const Big& a, const Big& b, const Big& m) { return big_mod(big_mul(a, b), m); }
+// base^e mod m, set-up time only (square and multiply over the bits of e; m.size() words)
+Big big_powmod(const Big& base, const Big& e, const Big& m) {
+  Big r(m.size(), 0); r[0] = 1;
+  r = big_mod(r, m);
+  const Big b = big_mod(base, m);
+  for (int i = big_bits(e) - 1; i >= 0; i--) {
+    r = big_mulmod(r, r, m);
+    if ((e[i >> 5] >> (i & 31)) & 1) r = big_mulmod(r, b, m);
+  }
+  return r;
+}
 Big big_sub_small(Big a, uint32_t k) { Big b(a.size(), 0); b[0] = k; big_sub(a, b); return a; }
 void big_add_inplace(Big& a, const Big& b) {   // same length; the carry out is dropped (callers keep a spare top word)
   uint64_t c = 0;
@@ -317,6 +328,14 @@ int sc_dgk_key_create(sc_ctx* ctx, const uint32_t* n_hptr, const uint32_t* g_hpt
   if (secret) {
     const Big p = big_trimmed(Big(p_hptr, p_hptr + pwords)), q = big_trimmed(Big(q_hptr, q_hptr + pwords));
     const Big vp = big_trimmed(Big(vp_hptr, vp_hptr + vwords)), vq = big_trimmed(Big(vq_hptr, vq_hptr + vwords));
+    // a secret key that does not belong to the public one would silently give randomizers that are not h^r mod n (the CRT halves
+    // reduce r modulo v_p, v_q) and zero tests that test nothing: check p q = n and that h has order dividing v_p (v_q) modulo p (q)
+    {
+      const Big pq = big_trimmed(big_mul(p, q));
+      if (pq.size() > (size_t)nwords || big_cmp(big_fit(pq, (size_t)nwords), k.n) != 0) return fail(ctx, SC_ERR_ARG, "sc_dgk_key_create: p * q != n");
+      if (!big_is_one(big_powmod(k.h, vp, p)) || !big_is_one(big_powmod(k.h, vq, q)))
+        return fail(ctx, SC_ERR_ARG, "sc_dgk_key_create: h^v_p mod p and h^v_q mod q must be 1 (the secret key does not match h)");
+    }
     rc = sc_mod_create(ctx, p.data(), (int)p.size(), &k.mod_p); if (rc) return rc;
     rc = reg_exp(ctx, vp, &k.exp_vp); if (rc) return rc;
     if (k.crt) {

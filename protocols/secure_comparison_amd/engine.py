@@ -64,7 +64,10 @@ class DgkKey:
 
 
 class Engine:
-    """One context per process/device.  Tensors are int32 views of uint32 words, shape [count, nwords]."""
+    """One library context (sc_ctx): one per process and device, or one per concurrent shard / session thread of a device.
+    Tensors are int32 views of uint32 words, shape [count, nwords].  An engine belongs to ONE host thread at a time: it orders its
+    work on one stream, reuses its temporaries from call to call, and its generator numbers its calls (rng_seed(key) is for tests:
+    re-seeding with the same key replays the same streams)."""
 
     def __init__(self, device: int | None = None) -> None:
         self.lib = _lib.load()

@@ -11,6 +11,7 @@ differences that make the arithmetic reproducible and batchable:
 """
 from __future__ import annotations
 
+import asyncio
 import secrets
 from dataclasses import dataclass
 from typing import Any, Sequence, cast
@@ -35,6 +36,10 @@ class AlicePlain:
 
 class Initiator:
     """Player Alice."""
+
+    # perform_secure_comparison runs Alice's steps as three library calls on one-element batches (True) or, like the reference's
+    # body, step by step through the ciphertext operator algebra (False: one launch per operator).  Same ciphertexts either way.
+    fuse_steps = True
 
     def __init__(self, l_maximum_bit_length: int, communicator: Communicator | None = None, other_party: str = "",
                  scheme_paillier: Paillier | None = None, scheme_dgk: DGK | None = None, session_id: int = 0) -> None:
@@ -70,6 +75,8 @@ class Initiator:
         pai, dgk = self.scheme_paillier, self.scheme_dgk
         x_enc = x if isinstance(x, PaillierCiphertext) else pai.unsafe_encrypt(x)
         y_enc = y if isinstance(y, PaillierCiphertext) else pai.unsafe_encrypt(y)
+        if self.fuse_steps:
+            return await self._perform_fused(x_enc, y_enc, sid)
 
         z_enc, r = Initiator.step_1(x_enc, y_enc, l, pai)
         z_enc.randomize()
@@ -90,16 +97,59 @@ class Initiator:
         beta_lt_alpha_enc = Initiator.step_6(delta_a, delta_b_enc)
         return Initiator.step_7(zeta_1_enc, zeta_2_enc, r, l, beta_lt_alpha_enc, pai)
 
+    async def _perform_fused(self, x_enc: PaillierCiphertext, y_enc: PaillierCiphertext, sid: int) -> PaillierCiphertext:
+        """The same exchange with Alice's steps as THREE library calls on one-element batches (sc_initiator_step1 / _step4 /
+        _step67) instead of one launch per ciphertext operator of steps 4d-4h (~10 l of them, each with its own upload,
+        synchronisation and download): identical ciphertexts -- the random values are drawn in the order the single steps draw
+        them (r; delta_A; rho_i; the shuffle), the randomizers come from the same pools, and output k of the shuffle takes the
+        randomizer the k-th `.randomize()` of SC/initiator.py:153-154 would have taken."""
+        pai, dgk, l = self.scheme_paillier, self.scheme_dgk, self.l_maximum_bit_length
+        e = pai.engine
+        nw, nd = pai.mod_n.nwords, dgk.mod_n.nwords
+        n, u = pai.public_key.n, dgk.public_key.u
+        tx, ty = e.upload([x_enc.get_value()], 2 * nw), e.upload([y_enc.get_value()], 2 * nw)
+        assert (1 << (l + 2)) < n // 2
+        r = secrets.randbelow(n)                                                   # step 1 (SC/initiator.py:250)
+        rz = e.upload([pai.get_randomness()], 2 * nw)                               # z_enc.randomize() (:109)
+        z, plain = Initiator.step_1_batch(tx, ty, l, pai, e.upload([r], nw), rz, randomizers_ready=True)
+        z_enc = PaillierCiphertext(e.download(z)[0], pai, fresh=True)
+        await self.communicator.send(self.other_party, z_enc, msg_id=f"step_1_session_{sid}")
+        d_enc, beta_is_enc = await self.communicator.recv(self.other_party, msg_id=f"step_4b_session_{sid}")
+        if len(beta_is_enc) != l:
+            raise ValueError(f"received {len(beta_is_enc)} encrypted bits, expected {l}")
+        planes = e.upload([d_enc.get_value()] + [b.get_value() for b in beta_is_enc], nd).reshape(l + 1, 1, nd)
+        assert 0 <= r < n                                                          # step 4c (:286-288)
+        _, delta_a = Initiator.step_4g()                                           # (:420)
+        rhos = [secrets.randbelow(u - 1) + 1 for _ in range(l + 1)]                 # step 4i (:512)
+        perm = Initiator.shuffle(list(range(l + 1)))                                # (:516): output k takes the blinded c at perm[k]
+        rand = [dgk.get_randomness() for _ in range(l + 1)]                         # the k-th c.randomize() (:153-154) ...
+        by_item = [0] * (l + 1)
+        for k, src in enumerate(perm):
+            by_item[src] = rand[k]                                                  # ... applied to the item that lands at output k
+        ew = (u.bit_length() + 31) // 32
+        c, _ = Initiator.step_4_batch(planes[0], planes[1:], plain, e.upload_u64([delta_a]), dgk, e.upload(rhos, ew).reshape(l + 1, 1, ew),
+                                      e.upload_u64(perm).reshape(1, l + 1), e.upload(by_item, nd).reshape(l + 1, 1, nd), randomizers_ready=True)
+        c_is_enc = [DGKCiphertext(v, dgk, fresh=True) for v in e.download(c.reshape(l + 1, nd))]
+        await self.communicator.send(self.other_party, c_is_enc, msg_id=f"step_4i_session_{sid}")
+        zeta_1_enc, zeta_2_enc, delta_b_enc = await self.communicator.recv(self.other_party, msg_id=f"step_5_session_{sid}")
+        three = e.upload([zeta_1_enc.get_value(), zeta_2_enc.get_value(), delta_b_enc.get_value()], 2 * nw)
+        res = Initiator.step_6_7_batch(e.upload_u64([delta_a]), three[2:3], three[0:1], three[1:2], plain, l, pai)
+        return PaillierCiphertext(e.download(res)[0], pai)
+
     async def perform_secure_comparison_batch(self, x_enc: torch.Tensor, y_enc: torch.Tensor, draws=None,
-                                              source: str = "device", engine=None, generator=None) -> torch.Tensor:
+                                              source: str = "device", engine=None, generator=None, chunks: int = 1) -> torch.Tensor:
         """B comparisons at once over the same four message exchanges, with batches on the wire as whole arrays
         (wire.py: the device arrays themselves when the transport's endpoints share a GPU, one pinned byte buffer otherwise).
         `draws` (batch.BatchDraws; Alice's fields) injects the randomness; otherwise every draw of SC/initiator.py:250, :420,
         :512, :223 and the 1 + (l+1) randomizer inputs per comparison (:205-210 scaled by B) are generated ON THE DEVICE by the
         engine's CSPRNG (`source="device"`; "torch" + `generator` = seeded, for reproducible runs) and consumed by the same fused
-        launches as injected draws.  x_enc, y_enc: [B][2nw] Paillier ciphertexts."""
+        launches as injected draws.  x_enc, y_enc: [B][2nw] Paillier ciphertexts.
+        chunks > 1: the batch travels as that many sub-sessions on the same connection (message ids `.._chunk_i`), announced by a
+        plan message; while one chunk's messages drain over the wire (copies on a stream of their own, wire.outgoing_async) the
+        event loop runs the other chunks' steps -- the pipelining a transport between two processes needs."""
         from . import wire
-        from .batch import draw_alice
+        from .batch import draw_alice, split_draws
+        from .distributed import shard_bounds
 
         if self.communicator is None:
             raise ValueError("Communicator not properly initialized.")
@@ -115,26 +165,44 @@ class Initiator:
             self._scheme_dgk = got_d
         elif self._scheme_dgk != got_d:
             raise ValueError("Readily available DGK scheme and received DGK scheme are different.")
-        pai, dgk, l = self.scheme_paillier, self.scheme_dgk, self.l_maximum_bit_length
+        pai = self.scheme_paillier
+        count = x_enc.shape[0]
+        wire.expect_array(x_enc, (count, 2 * pai.mod_n.nwords), "x_enc")
+        wire.expect_array(y_enc, (count, 2 * pai.mod_n.nwords), "y_enc")
+        chunks = max(1, min(int(chunks), count))
+        if chunks == 1:
+            return await self._batch_session(f"session_{sid}", x_enc, y_enc, draws, source, generator, None)
+        bounds = [shard_bounds(count, i, chunks) for i in range(chunks)]
+        await comm.send(self.other_party, wire.pack_plan([b - a for a, b in bounds]), msg_id=f"step_1_batch_session_{sid}")
+        parts = [None] * chunks if draws is None else split_draws(draws, bounds)
+        out = torch.empty_like(x_enc)
+        await asyncio.gather(*(self._batch_session(f"session_{sid}_chunk_{i}", x_enc[a:b], y_enc[a:b], parts[i], source, generator, out[a:b])
+                               for i, (a, b) in enumerate(bounds)))
+        return out
+
+    async def _batch_session(self, tag: str, x_enc: torch.Tensor, y_enc: torch.Tensor, draws, source: str, generator, out) -> torch.Tensor:
+        """One (sub-)session of the batched protocol: Alice's steps around the four message exchanges, message ids `.._{tag}`."""
+        from . import wire
+        from .batch import draw_alice
+
+        comm, pai, dgk, l = self.communicator, self.scheme_paillier, self.scheme_dgk, self.l_maximum_bit_length
         dev, count = x_enc.device, x_enc.shape[0]
         nw_p, nw_d = pai.mod_n.nwords, dgk.mod_n.nwords
-        wire.expect_array(x_enc, (count, 2 * nw_p), "x_enc")
-        wire.expect_array(y_enc, (count, 2 * nw_p), "y_enc")
         if draws is None:
             draws = draw_alice(count, l, pai, dgk, source, generator)
         z_enc, plain = Initiator.step_1_batch(x_enc, y_enc, l, pai, draws.r, draws.rho_z)
-        await comm.send(self.other_party, wire.outgoing(comm, z_enc), msg_id=f"step_1_batch_session_{sid}")
-        d_enc, beta_enc = wire.incoming(await comm.recv(self.other_party, msg_id=f"step_4b_batch_session_{sid}"), dev, expect=2)
+        await comm.send(self.other_party, await wire.outgoing_async(comm, z_enc), msg_id=f"step_1_batch_{tag}")
+        d_enc, beta_enc = wire.incoming(await comm.recv(self.other_party, msg_id=f"step_4b_batch_{tag}"), dev, expect=2)
         d_enc = wire.expect_array(d_enc, (count, nw_d), "[d]")                      # sizes come from this side's l and B,
         beta_enc = wire.expect_array(beta_enc, (l, count, nw_d), "[beta_i]")        # never from the message
         c, _ = Initiator.step_4_batch(d_enc, beta_enc, plain, draws.delta_a, dgk, draws.rhos, draws.permutation, draws.r_alice_dgk)
         if draws.permutation is not None and not bool(Initiator.permutation_is_valid(draws.permutation)):
             raise ValueError("permutation: a row is not a permutation of the l + 1 positions")   # before anything is sent
-        await comm.send(self.other_party, wire.outgoing(comm, c), msg_id=f"step_4i_batch_session_{sid}")
-        zeta_1, zeta_2, delta_b_enc = wire.incoming(await comm.recv(self.other_party, msg_id=f"step_5_batch_session_{sid}"), dev, expect=3)
+        await comm.send(self.other_party, await wire.outgoing_async(comm, c), msg_id=f"step_4i_batch_{tag}")
+        zeta_1, zeta_2, delta_b_enc = wire.incoming(await comm.recv(self.other_party, msg_id=f"step_5_batch_{tag}"), dev, expect=3)
         zeta_1, zeta_2, delta_b_enc = (wire.expect_array(t, (count, 2 * nw_p), name) for t, name in
                                        ((zeta_1, "[[zeta_1]]"), (zeta_2, "[[zeta_2]]"), (delta_b_enc, "[[delta_B]]")))
-        return Initiator.step_6_7_batch(draws.delta_a, delta_b_enc, zeta_1, zeta_2, plain, l, pai)   # one inversion pass
+        return Initiator.step_6_7_batch(draws.delta_a, delta_b_enc, zeta_1, zeta_2, plain, l, pai, out)   # one inversion pass
 
     async def receive_encryption_schemes(self, session_id: int = 1) -> None:
         """Receive Bob's public schemes; a pre-set scheme must match (SC/initiator.py:177-203)."""

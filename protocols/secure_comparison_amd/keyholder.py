@@ -31,6 +31,8 @@ class BobPlain:
 class KeyHolder:
     """Player Bob."""
 
+    fuse_steps = True      # see Initiator.fuse_steps
+
     def __init__(self, l_maximum_bit_length: int, communicator: Communicator | None = None, other_party: str = "",
                  scheme_paillier: Paillier | None = None, scheme_dgk: DGK | None = None, session_id: int = 0) -> None:
         self.l_maximum_bit_length = l_maximum_bit_length
@@ -65,6 +67,9 @@ class KeyHolder:
         pai, dgk = self.scheme_paillier, self.scheme_dgk
 
         z_enc = await self.communicator.recv(self.other_party, msg_id=f"step_1_session_{sid}")
+        if self.fuse_steps:
+            await self._perform_fused(z_enc, sid)
+            return
         z, beta = KeyHolder.step_2(z_enc, l, pai)
         d_enc = KeyHolder.step_4a(z, dgk, pai, l)
         beta_is_enc = KeyHolder.step_4b(beta, l, dgk)
@@ -79,36 +84,87 @@ class KeyHolder:
             ct.randomize()
         await self.communicator.send(self.other_party, (zeta_1_enc, zeta_2_enc, delta_b_enc), msg_id=f"step_5_session_{sid}")
 
+    async def _perform_fused(self, z_enc: PaillierCiphertext, sid: int) -> None:
+        """Bob's steps as TWO library calls on one-element batches (sc_keyholder_step2_4b, sc_keyholder_step4j_5) with the
+        randomizers taken from the pools in the order the single `.randomize()` calls take them: identical ciphertexts."""
+        pai, dgk, l = self.scheme_paillier, self.scheme_dgk, self.l_maximum_bit_length
+        e = pai.engine
+        nw, nd = pai.mod_n.nwords, dgk.mod_n.nwords
+        rand = e.upload([dgk.get_randomness() for _ in range(l + 1)], nd).reshape(l + 1, 1, nd)       # [d] first, then [beta_i] (:106-108)
+        plain, d, beta = KeyHolder.step_2_4b_batch(e.upload([z_enc.peek_value()], 2 * nw), l, pai, dgk, rand, randomizers_ready=True)
+        d_enc = DGKCiphertext(e.download(d)[0], dgk, fresh=True)
+        beta_is_enc = [DGKCiphertext(v, dgk, fresh=True) for v in e.download(beta.reshape(l, nd))]
+        await self.communicator.send(self.other_party, (d_enc, beta_is_enc), msg_id=f"step_4b_session_{sid}")
+        c_is_enc = await self.communicator.recv(self.other_party, msg_id=f"step_4i_session_{sid}")
+        if len(c_is_enc) != l + 1:
+            raise ValueError(f"received {len(c_is_enc)} blinded values, expected {l + 1}")
+        c = e.upload([ct.peek_value() for ct in c_is_enc], nd).reshape(l + 1, 1, nd)
+        rho3 = e.upload([pai.get_randomness() for _ in range(3)], 2 * nw)                                # zeta_1, zeta_2, delta_B (:126-128)
+        _, z1, z2, db = KeyHolder.step_4j_5_batch(c, plain, pai, dgk, rho3, randomizers_ready=True)
+        out = tuple(PaillierCiphertext(e.download(t)[0], pai, fresh=True) for t in (z1, z2, db))
+        await self.communicator.send(self.other_party, out, msg_id=f"step_5_session_{sid}")
+
     async def perform_secure_comparison_batch(self, draws=None, source: str = "device", generator=None) -> None:
         """Bob's side of Initiator.perform_secure_comparison_batch.  `draws` (batch.BatchDraws; Bob's fields) injects
         the randomizer inputs; otherwise the 3 Paillier + (l+1) DGK randomizer inputs per comparison (SC/keyholder.py:174-179
-        scaled by B) are drawn on the device by the engine's CSPRNG and consumed by the same fused launches."""
+        scaled by B) are drawn on the device by the engine's CSPRNG and consumed by the same fused launches.  When Alice
+        announces a chunked batch (wire.pack_plan as the first message) the chunks are served as concurrent sub-sessions."""
+        import asyncio
+
         from . import wire
-        from ._views import cat_rows
-        from .batch import draw_bob
+        from .batch import split_draws
 
         if self.communicator is None:
             raise ValueError("Communicator not properly initialized.")
         comm = self.communicator
         self.session_id += 1
         sid = self.session_id
-        pai, dgk, l = self.scheme_paillier, self.scheme_dgk, self.l_maximum_bit_length
+        pai, dgk = self.scheme_paillier, self.scheme_dgk
         await comm.send(self.other_party, wire.pack_public_schemes(pai, dgk), msg_id=f"schemes_batch_session_{sid}")
+        first = await comm.recv(self.other_party, msg_id=f"step_1_batch_session_{sid}")
+        sizes = wire.plan_of(first)
+        if sizes is None:
+            await self._batch_session(f"session_{sid}", first, draws, source, generator)
+            return
+        parts = [None] * len(sizes)
+        if draws is not None:
+            if draws.r_bob_dgk.shape[1] != sum(sizes):
+                raise ValueError(f"draws for {draws.r_bob_dgk.shape[1]} comparisons, the plan announces {sum(sizes)}")
+            bounds, start = [], 0
+            for n in sizes:
+                bounds.append((start, start + n))
+                start += n
+            parts = split_draws(draws, bounds)
+        await asyncio.gather(*(self._batch_session(f"session_{sid}_chunk_{i}", None, parts[i], source, generator, expect_count=n)
+                               for i, n in enumerate(sizes)))
+
+    async def _batch_session(self, tag: str, first, draws, source: str, generator, expect_count: int | None = None) -> None:
+        """One (sub-)session: Bob's steps around the four message exchanges with message ids `.._{tag}`; `first` is the step-1
+        message when it has been received already."""
+        from . import wire
+        from ._views import cat_rows
+        from .batch import draw_bob
+
+        comm, pai, dgk, l = self.communicator, self.scheme_paillier, self.scheme_dgk, self.l_maximum_bit_length
         dev = pai.engine.device
-        (z_enc,) = wire.incoming(await comm.recv(self.other_party, msg_id=f"step_1_batch_session_{sid}"), dev, expect=1)
+        if first is None:
+            first = await comm.recv(self.other_party, msg_id=f"step_1_batch_{tag}")
+        (z_enc,) = wire.incoming(first, dev, expect=1)
         if not isinstance(z_enc, torch.Tensor) or z_enc.dim() != 2:
             raise ValueError(f"[[z]]: received shape {tuple(getattr(z_enc, 'shape', ()))}, expected [B][{2 * pai.mod_n.nwords}]")
         count = z_enc.shape[0]                       # the batch size is Alice's to choose; everything else is checked against it
+        if expect_count is not None and count != expect_count:
+            raise ValueError(f"[[z]]: {count} comparisons in a chunk the plan announced with {expect_count}")
         z_enc = wire.expect_array(z_enc, (count, 2 * pai.mod_n.nwords), "[[z]]")
         if draws is None:
             draws = draw_bob(count, l, pai, dgk, source, generator)
         plain, d_enc, beta_enc = KeyHolder.step_2_4b_batch(z_enc, l, pai, dgk, draws.r_bob_dgk)
-        await comm.send(self.other_party, wire.outgoing(comm, d_enc, beta_enc), msg_id=f"step_4b_batch_session_{sid}")
-        (c_enc,) = wire.incoming(await comm.recv(self.other_party, msg_id=f"step_4i_batch_session_{sid}"), dev, expect=1)
+        await comm.send(self.other_party, await wire.outgoing_async(comm, d_enc, beta_enc), msg_id=f"step_4b_batch_{tag}")
+        (c_enc,) = wire.incoming(await comm.recv(self.other_party, msg_id=f"step_4i_batch_{tag}"), dev, expect=1)
         c_enc = wire.expect_array(c_enc, (l + 1, count, dgk.mod_n.nwords), "[c_i]")
         _, zeta_1_enc, zeta_2_enc, delta_b_enc = KeyHolder.step_4j_5_batch(
             c_enc, plain, pai, dgk, cat_rows([draws.rho_zeta_1, draws.rho_zeta_2, draws.rho_delta_b]))
-        await comm.send(self.other_party, wire.outgoing(comm, zeta_1_enc, zeta_2_enc, delta_b_enc), msg_id=f"step_5_batch_session_{sid}")
+        await comm.send(self.other_party, await wire.outgoing_async(comm, zeta_1_enc, zeta_2_enc, delta_b_enc), msg_id=f"step_5_batch_{tag}")
 
     async def make_and_send_encryption_schemes(self, session_id: int = 1, key_length_paillier: int = 2048,
                                                v_bits_dgk: int = 160, n_bits_dgk: int = 2048) -> None:

@@ -47,28 +47,39 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
-def _kfd_gpu_nodes(root: str = "/sys/class/kfd/kfd/topology/nodes") -> int | None:
-    """GPU nodes the amdgpu driver lists (nodes with SIMDs; CPU nodes have simd_count 0); None when the files are absent."""
+def _kfd_gpu_nodes(root: str = "/sys/class/kfd/kfd/topology/nodes", dri_root: str = "/dev/dri") -> int | None:
+    """GPU nodes the amdgpu driver lists AND this process may open: nodes with SIMDs (CPU nodes have simd_count 0) whose render
+    node /dev/dri/renderD<drm_render_minor> is readable and writable here -- sysfs lists every GPU of the host even when a
+    container or lease exposes only some of their device files.  A node without a drm_render_minor line counts (older drivers).
+    None when the topology files are absent."""
     files = glob.glob(os.path.join(root, "*", "properties"))
     if not files:
         return None
     n = 0
     for f in files:
+        simds, minor = 0, None
         try:
             for line in open(f):
-                if line.startswith("simd_count"):
-                    n += int(line.split()[1]) > 0
-                    break
-        except OSError:
+                parts = line.split()
+                if len(parts) >= 2 and parts[0] == "simd_count":
+                    simds = int(parts[1])
+                elif len(parts) >= 2 and parts[0] == "drm_render_minor":
+                    minor = int(parts[1])
+        except (OSError, ValueError):
             continue
+        if simds <= 0:
+            continue
+        if minor is not None and minor > 0 and not os.access(os.path.join(dri_root, f"renderD{minor}"), os.R_OK | os.W_OK):
+            continue
+        n += 1
     return n
 
 
-def visible_gpus(kfd_root: str = "/sys/class/kfd/kfd/topology/nodes") -> int:
+def visible_gpus(kfd_root: str = "/sys/class/kfd/kfd/topology/nodes", dri_root: str = "/dev/dri") -> int:
     """Number of GPUs this process's children could use, WITHOUT initialising the HIP / HSA runtime in this process: the
     driver's topology files, narrowed by the *_VISIBLE_DEVICES variables.  Only when those files do not exist (no amdgpu
     driver: the CPU test tier) does it ask torch, whose answer is 0 there without loading a runtime."""
-    n = _kfd_gpu_nodes(kfd_root)
+    n = _kfd_gpu_nodes(kfd_root, dri_root)
     if n is None:
         import torch
 
@@ -104,8 +115,9 @@ def spawn_ranks(script: str, argv: Sequence[str], nranks: int, *, need_gpus: boo
     otherwise the first failing rank's exit code: the remaining ranks are terminated, killed if they do not exit within
     `grace_s`, and the failing rank's last stderr lines are printed by the parent.  `timeout_s` bounds the whole job (exit code
     124).  With `need_gpus` the node must show at least `nranks` GPUs, else SystemExit(2) before anything is started.
-    The children inherit the environment as it is (HSA_ENABLE_IPC_MODE_LEGACY included when the operator exported it; this
-    launcher sets it only on request through `extra_env`)."""
+    The children get HSA_ENABLE_IPC_MODE_LEGACY=0 unless the operator exported another value (dmabuf IPC: what RCCL needs between
+    the ranks of a node on hosts whose driver supports nothing else -- without it rank-to-rank buffer sharing fails with
+    `hipIpcGetMemHandle: invalid argument`); `extra_env` overrides anything."""
     if nranks < 1:
         raise SystemExit("the rank count must be at least 1")
     if need_gpus:
@@ -120,6 +132,7 @@ def spawn_ranks(script: str, argv: Sequence[str], nranks: int, *, need_gpus: boo
             env = dict(os.environ)
             env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks), MASTER_ADDR="127.0.0.1",
                        MASTER_PORT=str(port), SC_AMD_RENDEZVOUS_TIMEOUT_S=str(RENDEZVOUS_TIMEOUT_S))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             if extra_env:
                 env.update(extra_env)
             log = os.path.join(tmp.name, f"rank{r}.stderr")

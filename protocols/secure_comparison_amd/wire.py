@@ -16,6 +16,13 @@ vector at B = 65536), so a batch travels in one of two forms, chosen by what the
 
   The receiver wraps the payload in place (`torch.frombuffer`) and issues one host-to-device copy per array.
 
+**Pipelining (round 4).**  A byte message of a batch is ~0.5 GB; copying it out of HBM takes ~10 ms during which a single
+session's GPU would idle.  `outgoing_async` therefore issues the device-to-host copies on a COPY STREAM of its own (after an event
+on the compute stream) and returns an awaitable: while one chunk's message drains over PCIe the event loop runs the next
+chunk's step (`Initiator.perform_secure_comparison_batch(chunks=k)` cuts a batch into k sub-sessions that share the connection;
+the key holder learns the plan from the first message, `pack_plan`).  `incoming` does the mirror image: host-to-device copies on
+the copy stream, the compute stream waits for their event.
+
 Either way nothing in a message is trusted: shapes and dtypes are checked against the bytes that arrived and then against
 what this party's own parameters (l, B, key sizes) dictate (`expect_array`).  Public keys travel as a small JSON document
 (integers as hex).  `STATS` accumulates the seconds and bytes spent packing / unpacking (bench.py reports the split)."""
@@ -23,6 +30,7 @@ from __future__ import annotations
 
 import json
 import struct
+import threading
 import time
 from dataclasses import dataclass
 from typing import Any, Sequence
@@ -62,12 +70,55 @@ def _header(t: torch.Tensor) -> bytes:
     return MAGIC + struct.pack("<BBH", _CODES[t.dtype], t.dim(), 0) + struct.pack(f"<{t.dim()}Q", *t.shape)
 
 
-def _pack(tensors: Sequence[torch.Tensor], framed: bool) -> memoryview:
-    """One host buffer for the whole message; every payload lands in it by a single copy from wherever the array lives."""
-    for t in tensors:
-        if t.is_cuda:     # the copies below wait for the producing kernels anyway; waiting here keeps STATS about the wire only
-            torch.cuda.current_stream(t.device).synchronize()
-            break
+_copy_streams: dict = {}
+
+
+def copy_stream(device: torch.device) -> "torch.cuda.Stream":
+    """The stream this thread's message copies run on (one per thread and device; never the compute stream)."""
+    key = (threading.get_ident(), torch.device(device).index)
+    if key not in _copy_streams:
+        _copy_streams[key] = torch.cuda.Stream(device=device)
+    return _copy_streams[key]
+
+
+class PendingMessage:
+    """A byte message whose payload copies are still in flight on the copy stream.  `await msg.wait()` yields to the event loop
+    until they are done and returns the buffer; the source arrays are kept alive until then."""
+
+    def __init__(self, raw: np.ndarray, event, keep: tuple, started: float) -> None:
+        self._raw, self._event, self._keep, self._t0 = raw, event, keep, started
+
+    def done(self) -> bool:
+        return self._event is None or self._event.query()
+
+    def result(self) -> memoryview:
+        """Blocking form."""
+        if self._event is not None:
+            self._event.synchronize()
+        return self._finish()
+
+    async def wait(self) -> memoryview:
+        import asyncio
+
+        spins = 0
+        while not self.done():
+            spins += 1
+            await asyncio.sleep(0 if spins < 200 else 0.0001)
+        return self._finish()
+
+    def _finish(self) -> memoryview:
+        if self._keep is not None:
+            STATS["pack_s"] += time.perf_counter() - self._t0        # issue to completion (overlapped with whatever ran meanwhile)
+            self._keep, self._event = None, None
+        return memoryview(self._raw)
+
+
+def _pack(tensors: Sequence[torch.Tensor], framed: bool, asynchronous: bool = False):
+    """One host buffer for the whole message; every payload lands in it by a single copy from wherever the array lives.
+    asynchronous: device payloads are copied on the copy stream and a PendingMessage is returned instead of the buffer."""
+    on_gpu = [t for t in tensors if t.is_cuda]
+    if on_gpu and not asynchronous:  # the copies below wait for the producing kernels anyway; waiting here keeps STATS about the wire only
+        torch.cuda.current_stream(on_gpu[0].device).synchronize()
     t0 = time.perf_counter()
     heads = [_header(t) for t in tensors]
     sizes = [len(h) + t.numel() * t.element_size() for h, t in zip(heads, tensors)]
@@ -79,6 +130,11 @@ def _pack(tensors: Sequence[torch.Tensor], framed: bool) -> memoryview:
     if framed:
         raw[0:4] = np.frombuffer(struct.pack("<I", len(tensors)), dtype=np.uint8)
         off = 4
+    side, keep = None, []
+    if on_gpu and asynchronous:
+        compute = torch.cuda.current_stream(on_gpu[0].device)
+        side = copy_stream(on_gpu[0].device)
+        side.wait_stream(compute)                     # the arrays are complete once everything queued so far has run
     for h, t, s in zip(heads, tensors, sizes):
         if framed:
             raw[off:off + 8] = np.frombuffer(struct.pack("<Q", s), dtype=np.uint8)
@@ -87,10 +143,23 @@ def _pack(tensors: Sequence[torch.Tensor], framed: bool) -> memoryview:
         nbytes = s - len(h)
         if nbytes:
             # the payload region viewed as bytes of the array's own dtype: one (device-to-)host copy, straight into place
-            buf[off + len(h):off + s].copy_(t.detach().contiguous().reshape(-1).view(torch.uint8), non_blocking=False)
+            src = t.detach().contiguous().reshape(-1).view(torch.uint8)
+            if side is not None and t.is_cuda:
+                with torch.cuda.stream(side):
+                    buf[off + len(h):off + s].copy_(src, non_blocking=True)
+                src.record_stream(side)
+                keep.append(src)
+            else:
+                buf[off + len(h):off + s].copy_(src, non_blocking=False)
         off += s
-    STATS["pack_s"] += time.perf_counter() - t0
     STATS["bytes"] += total
+    if asynchronous:
+        ev = None
+        if side is not None:
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return PendingMessage(raw, ev, (buf, tuple(keep)), t0)
+    STATS["pack_s"] += time.perf_counter() - t0
     return memoryview(raw)
 
 
@@ -114,6 +183,41 @@ def outgoing(communicator: Any, *tensors: torch.Tensor):
     return pack_many(*tensors)
 
 
+async def outgoing_async(communicator: Any, *tensors: torch.Tensor):
+    """`outgoing` for a coroutine: a byte message's device-to-host copies run on the copy stream while the event loop goes on
+    with other sub-sessions; resolves to the finished message."""
+    if carries_device_arrays(communicator):
+        return outgoing(communicator, *tensors)
+    return await _pack(tensors, framed=True, asynchronous=True).wait()
+
+
+PLAN_MAGIC = b"SCPLAN1"
+
+
+def pack_plan(sizes: Sequence[int]) -> bytes:
+    """First message of a chunked batch: how many sub-sessions follow and how many comparisons each carries."""
+    return PLAN_MAGIC + json.dumps({"chunks": [int(n) for n in sizes]}).encode()
+
+
+def plan_of(message: Any) -> list[int] | None:
+    """The chunk sizes if `message` is a plan (pack_plan), else None -- then it is the step-1 message of an unchunked batch."""
+    if isinstance(message, DeviceArrays):
+        return None
+    try:
+        mv = memoryview(message).cast("B")
+    except TypeError:
+        return None
+    if len(mv) < len(PLAN_MAGIC) or bytes(mv[:len(PLAN_MAGIC)]) != PLAN_MAGIC:
+        return None
+    try:
+        sizes = json.loads(bytes(mv[len(PLAN_MAGIC):]).decode())["chunks"]
+    except (ValueError, KeyError, TypeError) as exc:
+        raise ValueError("malformed batch plan") from exc
+    if not isinstance(sizes, list) or not 1 <= len(sizes) <= 64 or not all(isinstance(n, int) and 0 < n <= 1 << 32 for n in sizes):
+        raise ValueError("malformed batch plan")
+    return sizes
+
+
 def incoming(message: Any, device: torch.device | str, expect: int) -> list[torch.Tensor]:
     """The arrays of a received message (either form), on `device`; exactly `expect` of them."""
     if isinstance(message, DeviceArrays):
@@ -134,6 +238,9 @@ def _as_view(buf: Any) -> memoryview:
         return memoryview(buf).cast("B")
     except TypeError as exc:
         raise ValueError("not a secure-comparison batch message") from exc
+
+
+_tls = threading.local()   # .inflight: (event, host view, message) of this thread's host-to-device copies that may still read a message's bytes
 
 
 def unpack_tensor(buf: Any, device: torch.device | str = "cpu") -> torch.Tensor:
@@ -165,7 +272,22 @@ def unpack_tensor(buf: Any, device: torch.device | str = "cpu") -> torch.Tensor:
             warnings.filterwarnings("ignore", message=".*not writable.*")
             host = torch.frombuffer(payload, dtype=torch.uint8).view(tdt).reshape(tuple(shape))   # wraps the received bytes in place
         dev = torch.device(device)
-        out = host.to(dev) if dev.type != "cpu" else host.clone()
+        if dev.type == "cpu":
+            out = host.clone()
+        else:
+            # on the copy stream, so that the transfer runs beside the kernels already queued on the compute stream (which then
+            # waits for it); from pinned memory the host does not wait either -- the message is kept alive by the array's copy
+            compute, side = torch.cuda.current_stream(dev), copy_stream(dev)
+            with torch.cuda.stream(side):
+                out = host.to(dev, non_blocking=True)
+            out.record_stream(compute)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            compute.wait_event(ev)
+            inflight = _tls.__dict__.setdefault("inflight", [])
+            inflight.append((ev, host, buf))
+            while inflight and inflight[0][0].query():
+                inflight.pop(0)
     STATS["unpack_s"] += time.perf_counter() - t0
     return out
 

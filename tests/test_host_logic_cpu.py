@@ -114,6 +114,52 @@ def test_interactive_protocol_exact_randomness_budget(world, x, y):
     assert not alice.scheme_paillier._pool and not alice.scheme_dgk._pool and not world[3]._pool and not world[4]._pool
 
 
+def _run_single(world, x, y, fused, seed):
+    """One interactive comparison with every `secrets` draw of both players replaced by a seeded stream; all wire values."""
+    import secrets
+
+    osk, od, eng, bob_p, bob_d = world
+    rng = random.Random(seed)
+    real = secrets.randbelow, secrets.randbits
+    secrets.randbelow, secrets.randbits = (lambda n: rng.randrange(n)), (lambda k: rng.getrandbits(k))
+    sent = {}
+
+    class Tap(DictionaryCommunicator):
+        async def send(self, party_id, message, msg_id):
+            flat = []
+            for m in (message if isinstance(message, tuple) else (message,)):
+                flat += [c.peek_value() for c in (m if isinstance(m, list) else [m]) if hasattr(c, "peek_value")]
+            sent[msg_id] = flat
+            await super().send(party_id, message, msg_id)
+
+    try:
+        box = {}
+        alice, bob = Initiator(L, Tap(box), "bob"), KeyHolder(L, Tap(box), "alice", bob_p, bob_d)
+        alice.fuse_steps = bob.fuse_steps = fused
+
+        async def go():
+            res, _ = await asyncio.gather(alice.perform_secure_comparison(x, y), bob.perform_secure_comparison())
+            return res
+
+        res = asyncio.run(go())
+    finally:
+        secrets.randbelow, secrets.randbits = real
+    assert not bob_p._pool and not bob_d._pool and not alice.scheme_dgk._pool and not alice.scheme_paillier._pool
+    return res.peek_value(), sent
+
+
+@pytest.mark.parametrize("x, y", [(23, 42), (42, 23), (-5, -5)])
+def test_fused_single_comparison_equals_the_operator_path(world, x, y):
+    """perform_secure_comparison through the step-level library calls on one-element batches (the default) sends and returns
+    the same ciphertexts, bit for bit, as the reference-shaped body that walks the ciphertext operator algebra step by step --
+    with the same random stream: every message of the exchange is compared, not only the result."""
+    fused, sent_f = _run_single(world, x, y, True, 99)
+    plain, sent_p = _run_single(world, x, y, False, 99)
+    assert sent_f.keys() == sent_p.keys() and all(sent_f[k] == sent_p[k] for k in sent_f if not k.startswith("schemes"))
+    assert fused == plain and world[3].decrypt(world[3]._ct_class(fused, world[3])) == int(x <= y)
+    assert _run_single(world, x, y, True, 100)[0] != fused          # another stream, other ciphertexts
+
+
 def test_parallel_sessions_are_namespaced(world):
     osk, od, eng, bob_p, bob_d = world
     box = {}
@@ -251,6 +297,49 @@ def test_batched_interactive_protocol_and_wire_format(world, device_tensors):
             (wire.STATS["device_arrays"] == 0 and wire.STATS["bytes"] > B * (2 * (L + 1) * 4 * bob_d.mod_n.nwords))
         assert alice.scheme_paillier == bob_p and alice.scheme_dgk == bob_d and not box
     assert seen[0] == seen[1] and seen[0] != seen[2]        # same key, same stream; another key, other ciphertexts
+
+
+@pytest.mark.parametrize("device_tensors", [True, False])
+def test_chunked_batch_equals_the_unchunked_one(world, device_tensors):
+    """A batch sent as k sub-sessions on one connection (Initiator.perform_secure_comparison_batch(chunks=k): plan message, message
+    ids `.._chunk_i`, the chunks' steps interleaving on the event loop while messages are packed asynchronously) gives the same
+    ciphertexts bit for bit as the single session with the same injected draws -- ragged chunk sizes, more chunks than
+    comparisons, and the key holder learning the plan from the first message alone."""
+    osk, od, eng, bob_p, bob_d = world
+    rng = random.Random(77)
+    B = 7
+    xs = [rng.randrange(1 << L) for _ in range(B)]
+    ys = [xs[i] if i % 3 == 0 else rng.randrange(1 << L) for i in range(B)]
+    x_enc = [osk.randomize(osk.enc_raw(x), 1 + rng.randrange(osk.n - 1)) for x in xs]
+    y_enc = [osk.randomize(osk.enc_raw(y), 1 + rng.randrange(osk.n - 1)) for y in ys]
+    nw = bob_p.mod_n.nwords
+    tx, ty = eng.upload(x_enc, 2 * nw), eng.upload(y_enc, 2 * nw)
+    drs = [o.draw(rng, L, osk, od, 50) for _ in range(B)]
+    draws = make_draws(eng, drs, L, nw, (od.u.bit_length() + 31) // 32, 2)
+    expect = [o.compare(a, b, L, osk, od, d, True) for a, b, d in zip(x_enc, y_enc, drs)]
+    for chunks, use_draws in ((1, True), (3, True), (7, True), (50, True), (2, False)):
+        box = {}
+        alice = Initiator(L, DictionaryCommunicator(box, device_tensors), "bob")
+        bob = KeyHolder(L, DictionaryCommunicator(box, device_tensors), "alice", bob_p, bob_d)
+
+        async def go():
+            res, _ = await asyncio.gather(alice.perform_secure_comparison_batch(tx, ty, draws if use_draws else None, engine=eng, chunks=chunks),
+                                          bob.perform_secure_comparison_batch(draws if use_draws else None))
+            return res
+
+        got = eng.download(asyncio.run(go()))
+        assert [osk.dec_raw(v) for v in got] == [int(x <= y) for x, y in zip(xs, ys)]
+        if use_draws:
+            assert got == expect
+        assert not box
+    # a plan that does not match the key holder's injected draws, and a chunk of another size than announced, are refused
+    from protocols.secure_comparison_amd import wire
+
+    with pytest.raises(ValueError):
+        wire.plan_of(wire.PLAN_MAGIC + b'{"chunks": [0]}')
+    with pytest.raises(ValueError):
+        wire.plan_of(wire.PLAN_MAGIC + b'not json')
+    assert wire.plan_of(wire.pack_many(tx)) is None and wire.plan_of(wire.pack_plan([4, 3])) == [4, 3]
 
 
 def test_bad_permutation_is_refused_before_the_send(world):

@@ -93,6 +93,36 @@ def test_gpu_count_comes_from_the_driver_files_not_from_hip(tmp_path, monkeypatc
     assert launcher.visible_gpus(str(tmp_path)) == 0
     assert launcher.host_threads_per_rank(1, 2) == min(2, os.cpu_count() or 1)
     assert launcher.host_threads_per_rank(10 ** 6, 2) == 1
+    # a lease that exposes only some of the host's GPUs: sysfs still lists all of them, but only nodes whose render node
+    # (/dev/dri/renderD<drm_render_minor>) this process may open count
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    dri = tmp_path / "dri"
+    dri.mkdir()
+    for i, minor in ((2, 128), (3, 129), (4, 130)):
+        (tmp_path / str(i) / "properties").write_text(f"simd_count 1024\ndrm_render_minor {minor}\n")
+    (dri / "renderD129").write_text("")
+    assert launcher.visible_gpus(str(tmp_path), str(dri)) == 1
+    (dri / "renderD130").write_text("")
+    assert launcher.visible_gpus(str(tmp_path), str(dri)) == 2
+
+
+def test_spawned_ranks_get_dmabuf_ipc_unless_the_operator_chose(tmp_path, monkeypatch):
+    """HSA_ENABLE_IPC_MODE_LEGACY=0 is what RCCL needs between the ranks of a node here: the launcher sets it for its children,
+    keeps a value the operator exported, and lets extra_env override both."""
+    from protocols.secure_comparison_amd import launcher
+
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    script = tmp_path / "w.py"
+    script.write_text("import os\nopen(os.environ['OUT'] + os.environ['RANK'], 'w').write(os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', 'unset'))\n")
+    out = str(tmp_path / "v")
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    assert launcher.spawn_ranks(str(script), [], 2, need_gpus=False, extra_env={"OUT": out}) == 0
+    assert open(out + "0").read() == "0" and open(out + "1").read() == "0"
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "1")
+    assert launcher.spawn_ranks(str(script), [], 1, need_gpus=False, extra_env={"OUT": out}) == 0 and open(out + "0").read() == "1"
+    assert launcher.spawn_ranks(str(script), [], 1, need_gpus=False, extra_env={"OUT": out, "HSA_ENABLE_IPC_MODE_LEGACY": "0"}) == 0
+    assert open(out + "0").read() == "0"
 
 
 def test_stuck_rank_is_killed_and_the_failure_is_named(tmp_path, monkeypatch, capfd):

@@ -51,7 +51,7 @@ def _keyholder_process(conn, root):
     eng = OracleEngine()
     bob = KeyHolder(L, PipeCommunicator(conn), "alice", Paillier(osk.n, osk.p, osk.q, engine=eng),
                     DGK(od.n, od.g, od.h, od.u, od.t, od.p, od.q, od.v_p, od.v_q, engine=eng, randomizer_bits=50))
-    for _ in range(2):
+    for _ in range(3):
         asyncio.run(bob.perform_secure_comparison_batch())
     conn.close()
 
@@ -70,14 +70,16 @@ def test_two_processes_bytes_only(keys):
         alice = Initiator(L, PipeCommunicator(here), "bob")
         rng = random.Random(17)
         nw = 32
-        for B in (6, 1):                             # two sessions on one connection: the session-numbered labels keep them apart
+        # three sessions on one connection: the session-numbered labels keep them apart; the last one travels as three chunks
+        # (plan message + `.._chunk_i` sub-sessions whose messages interleave on the pipe)
+        for B, chunks in ((6, 1), (1, 1), (7, 3)):
             xs = [rng.randrange(1 << L) for _ in range(B)]
             ys = [xs[i] if i % 3 == 0 else rng.randrange(1 << L) for i in range(B)]
             tx = eng.upload([osk.randomize(osk.enc_raw(x), 1 + rng.randrange(osk.n - 1)) for x in xs], 2 * nw)
             ty = eng.upload([osk.randomize(osk.enc_raw(y), 1 + rng.randrange(osk.n - 1)) for y in ys], 2 * nw)
-            res = asyncio.run(alice.perform_secure_comparison_batch(tx, ty, engine=eng))
+            res = asyncio.run(alice.perform_secure_comparison_batch(tx, ty, engine=eng, chunks=chunks))
             assert [osk.dec_raw(v) for v in eng.download(res)] == [int(x <= y) for x, y in zip(xs, ys)]
-        assert alice.session_id == 2 and alice.scheme_paillier.public_key.n == osk.n and alice.scheme_paillier.secret_key is None
+        assert alice.session_id == 3 and alice.scheme_paillier.public_key.n == osk.n and alice.scheme_paillier.secret_key is None
     finally:
         child.join(30)
         if child.is_alive():
