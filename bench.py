@@ -26,7 +26,8 @@ sys.path.insert(0, ROOT)
 
 KEYS = os.path.join(ROOT, "tests", "golden", "keys.json")
 MAX_CLOCK_HZ = 2.4e9   # MI355X peak engine clock (MI355X_MICROARCH.md)
-DEFAULT_FB_WINDOW = 16  # fixed-base window of the tables for h: 0.66 GB per GPU (window 20 = 6.2 GB buys +0.9 %: window_sensitivity)
+DEFAULT_FB_WINDOW = 20  # fixed-base window of the tables for h: 6.2 GB per GPU of 288 (21 table products per DGK randomizer instead of the 26 of
+                        # window 16 / 0.66 GB: +1.0 % on the whole step in a same-box A/B, profiles/r04_ab_vs_round2_tag.txt; window_sensitivity in the line)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 

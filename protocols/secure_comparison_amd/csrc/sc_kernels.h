@@ -286,6 +286,21 @@ __global__ void __launch_bounds__(64, (G == 1 && L == 37) ? 2 : (L == 27 ? SC_L2
           gp.normalize(acc, sub);
           break;
         }
+        case OP_TAKEFLAG: {
+          // one lane of the group reads, resets and hands on the flag word (same thread, same address: program order holds)
+          uint32_t v = 0;
+          if (gp.j == 0 && live) {
+            unsigned long long* accb = (unsigned long long*)args.ext[op.w1 & 0xf].ptr + idx;
+            const unsigned long long w = *accb;
+            *accb = 0ull;
+            ((unsigned long long*)args.ext[op.w2 & 0xf].ptr)[idx] = w;
+            v = (uint32_t)w & 1u;
+          }
+#pragma unroll
+          for (int l = 0; l < L; l++) acc[l] = 0;
+          acc[0] = v;                       // lanes j > 0 hold the higher limbs: zero
+          break;
+        }
         case OP_QUOT: {
           uint32_t r[L], quot[L], zero[L];
 #pragma unroll

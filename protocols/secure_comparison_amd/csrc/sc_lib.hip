@@ -329,7 +329,29 @@ inline bool small_enough_to_fork(const sc_ctx* ctx, const Mod& m, uint64_t count
   return (count + per_wave - 1) / per_wave <= (uint64_t)ctx->num_cu * 4 / (uint64_t)ctx->chip_share;
 }
 
-enum TmpSlot { TMP_PARK = 1, TMP_CRT = 3, TMP_PAIR = 4, TMP_INV_MEMBERS = 5, TMP_INV_BASE = 16 /* + 2*depth, + 2*depth+1 */ };
+enum TmpSlot { TMP_PARK = 1, TMP_ANYFLAG = 2, TMP_CRT = 3, TMP_PAIR = 4, TMP_INV_MEMBERS = 5, TMP_INV_BASE = 16 /* + 2*depth, + 2*depth+1 */ };
+
+// A u64 accumulator array of the context that is ZERO whenever no step is using it: cleared when it is (re)allocated, reset by its
+// reader afterwards (OP_TAKEFLAG).  The zero tests of step 4j OR their verdicts into it; no clearing launch inside a step.
+int zero_kept_flags(sc_ctx* ctx, uint64_t count, uint64_t** out) {
+  auto& e = ctx->tmp[TMP_ANYFLAG + (ctx->in_aux ? 1000 : 0)];
+  const size_t bytes = (size_t)count * sizeof(uint64_t);
+  if (e.second < bytes) {
+    if (e.first) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(e.first)); e.first = nullptr; e.second = 0; }
+    const size_t want = bytes + bytes / 8 + 256;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMalloc(&e.first, want));
+    e.second = want;
+    HIPCHK(ctx, hipMemsetAsync(e.first, 0, want, ctx->stream));
+  }
+  *out = (uint64_t*)e.first;
+  return SC_OK;
+}
+
+void drop_zero_kept_flags(sc_ctx* ctx) {      // forget the accumulator: the next use allocates and clears a new one
+  auto& e = ctx->tmp[TMP_ANYFLAG + (ctx->in_aux ? 1000 : 0)];
+  if (e.first) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(e.first); e.first = nullptr; e.second = 0; }
+}
 
 // `count` verdict words in pinned, device-visible host memory (grow-only, per stream of the context)
 int status_words(sc_ctx* ctx, size_t count, int** out) {
@@ -902,14 +924,16 @@ int sc_modmul_const_sel(sc_ctx* ctx, int mod, const uint32_t* a, int cst0, int c
 
 static int onelane_for(sc_ctx* ctx, int mod, uint64_t count);
 
+// any_flags_clean: the caller guarantees that any_flags[0 .. inner) is zero already (a context-owned accumulator that its reader
+// resets, OP_TAKEFLAG): no clearing launch
 static int modexp_shared_impl(sc_ctx* ctx, int mod, int exp, const uint32_t* x, int x_words, const uint32_t* mul_into,
-                              uint32_t* out, uint8_t* flags, uint64_t count, uint64_t* any_flags, uint64_t inner) {
+                              uint32_t* out, uint8_t* flags, uint64_t count, uint64_t* any_flags, uint64_t inner, bool any_flags_clean = false) {
   if (ctx && count == 0) return SC_OK;  // empty batch: nothing to do (pointers may be null)
   if (!valid_mod(ctx, mod) || exp < 0 || exp >= (int)ctx->exps.size() || !x || (!out && !flags && !any_flags))
     return fail(ctx, SC_ERR_ARG, "sc_modexp_shared: bad argument");
   if (any_flags) {
     if (inner == 0 || count % inner != 0) return fail(ctx, SC_ERR_ARG, "sc_modexp_shared_isone_any: count must be a multiple of the inner count");
-    HIPCHK(ctx, hipMemsetAsync(any_flags, 0, inner * sizeof(uint64_t), ctx->stream));
+    if (!any_flags_clean) HIPCHK(ctx, hipMemsetAsync(any_flags, 0, inner * sizeof(uint64_t), ctx->stream));
   }
   if (ctx->exps[exp].bits > 64) mod = onelane_for(ctx, mod, count);   // long exponentiations of a chip-filling batch: one-lane twin
   const Mod& m = ctx->mods[mod];
@@ -1579,7 +1603,7 @@ static std::mutex g_cal_mutex;
 static std::map<int, OneLaneCal> g_cal;           // by device
 
 static int modexp_shared_impl(sc_ctx* ctx, int mod, int exp, const uint32_t* x, int x_words, const uint32_t* mul_into,
-                              uint32_t* out, uint8_t* flags, uint64_t count, uint64_t* any_flags, uint64_t inner);
+                              uint32_t* out, uint8_t* flags, uint64_t count, uint64_t* any_flags, uint64_t inner, bool any_flags_clean);
 
 static int onelane_calibrate(sc_ctx* ctx, OneLaneCal* out) {
   OneLaneCal c;
@@ -1606,7 +1630,7 @@ static int onelane_calibrate(sc_ctx* ctx, OneLaneCal* out) {
     double best = 1e30;
     for (int rep = 0; rep < 2; rep++) {
       HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
-      int r = modexp_shared_impl(ctx, mod, exp, x, nw, nullptr, y, nullptr, count, nullptr, 0); if (r) return r;
+      int r = modexp_shared_impl(ctx, mod, exp, x, nw, nullptr, y, nullptr, count, nullptr, 0, false); if (r) return r;
       HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
       HIPCHK(ctx, hipEventSynchronize(e1));
       float t = 0; HIPCHK(ctx, hipEventElapsedTime(&t, e0, e1));

@@ -383,6 +383,58 @@ static int dgk_randomize_impl(sc_ctx* ctx, const DgkKey& k, const uint32_t* c, c
   int rc;
   if (!k.secret || !k.crt) {
     rc = sc_fixedbase_pow(ctx, k.fbt_h, r, ewords, c, out, count); if (rc) return rc;
+  } else if (!c) {
+    // Key holder, CRT (SC/keyholder.py:106-108): h^r mod q, then h^r mod p with the first half of the recombination in the same
+    // launch -- t = (a_p - a_q) q^-1 mod p leaves the fixed-base program instead of a_p --, then a_q + q t with the g^bit factor of
+    // the unrandomized encryption in the same launch: five launches over the l + 1 values of every comparison instead of seven
+    // (each pass over the batch costs a load, a canonical store and the launch's ramp, whatever it multiplies).  Same residues.
+    uint32_t *r_red, *tq, *a_q;
+    const int pw = ctx->mods[k.hp.m].nwords, qw = ctx->mods[k.hq.m].nwords;
+    const int vpw = ctx->mods[k.hp.m_v].nwords, vqw = ctx->mods[k.hq.m_v].nwords;
+    rc = tmp_words(ctx, TMP_S_A, count * std::max(vpw, vqw), &r_red); if (rc) return rc;
+    rc = tmp_words(ctx, TMP_S_B, count * pw, &tq); if (rc) return rc;
+    rc = tmp_words(ctx, TMP_S_C, count * qw, &a_q); if (rc) return rc;
+    rc = sc_modexp_shared(ctx, k.hq.m_v, k.exp_one, r, ewords, nullptr, r_red, count); if (rc) return rc;                 // r mod v_q
+    rc = sc_fixedbase_pow(ctx, k.hq.fbt, r_red, vqw, nullptr, a_q, count); if (rc) return rc;                               // a_q = h^r mod q
+    rc = sc_modexp_shared(ctx, k.hp.m_v, k.exp_one, r, ewords, nullptr, r_red, count); if (rc) return rc;                 // r mod v_p
+    {
+      const Fbt f = ctx->fbts[k.hp.fbt];
+      const Mod mp = ctx->mods[k.hp.m];
+      std::string key = "fbcrt1:" + std::to_string(k.hp.fbt) + ":" + std::to_string(k.c_k) + ":" + std::to_string(k.c_negk) + ":" + std::to_string(qw);
+      auto it = ctx->progs.find(key);
+      if (it == ctx->progs.end()) {
+        Builder bd; const int ck = bd.use_const(k.c_k), cn = bd.use_const(k.c_negk);
+        int kc = -1;
+        if (qw > mp.nwords) { int cid; rc = get_const_kred(ctx, k.hp.m, &cid); if (rc) return rc; kc = bd.use_const(cid); }
+        bd.loadt_fbt(0, 0, f.window, 0);
+        for (int j = 1; j < f.nwin; j++) bd.mul_fbt(0, j * f.window, f.window, j);
+        bd.redc();                                                                         // a_p = h^r mod p
+        bd.mul_const(ck); bd.stt(0);                                                       // a_p k,  k = q^-1 mod p
+        if (qw > mp.nwords) emit_load_reduced(ctx, mp, bd, 1, qw, kc); else bd.loadw(1, 0, 0, qw);
+        bd.mul_const(cn); bd.addt(0);                                                      // + a_q (p - k)
+        bd.storew(2); bd.end();
+        Prog pr; rc = finalize_prog(ctx, mp, bd, &pr); if (rc) return rc;
+        it = ctx->progs.emplace(key, pr).first;
+      }
+      VmExt ex[3] = {mk_ext(r_red, vpw, vpw), mk_ext(a_q, qw, qw), mk_ext(tq, mp.nwords, mp.nwords)};
+      rc = run_vm(ctx, k.hp.m, it->second, ex, 3, count, f.d_rows); if (rc) return rc;
+    }
+    {
+      const Mod mn = ctx->mods[k.mod_n];
+      std::string key = "fbcrt2:" + std::to_string(k.mod_n) + ":" + std::to_string(k.c_mq) + ":" + std::to_string(pw) + ":" + std::to_string(qw) + (bits ? ":g" + std::to_string(k.cst_g) : "");
+      auto it = ctx->progs.find(key);
+      if (it == ctx->progs.end()) {
+        Builder bd; const int cm = bd.use_const(k.c_mq);
+        bd.loadw(0, 0, 0, pw); bd.mul_const(cm);                                           // q t  (< p q: exact)
+        bd.addw(1, 0, 0, qw);                                                              // + a_q = h^r mod n
+        if (bits) { const int cg = bd.use_const(k.cst_g); bd.emit(OP_MUL, AK_CONSTSEL, 0, 3, (uint32_t)1 | ((uint32_t)cg << 8)); bd.muls++; }   // times g where the bit is set
+        bd.storew(2); bd.end();
+        Prog pr; rc = finalize_prog(ctx, mn, bd, &pr); if (rc) return rc;
+        it = ctx->progs.emplace(key, pr).first;
+      }
+      VmExt ex[4] = {mk_ext(tq, pw, pw), mk_ext(a_q, qw, qw), mk_ext(out, mn.nwords, mn.nwords), mk_ext(bits, 0, 0)};
+      return run_vm(ctx, k.mod_n, it->second, ex, 4, count);
+    }
   } else {
     uint32_t *r_red, *part_p, *part_q;
     const int pw = ctx->mods[k.hp.m].nwords, qw = ctx->mods[k.hq.m].nwords;
@@ -572,15 +624,38 @@ int sc_keyholder_step4j_5(sc_ctx* ctx, int paillier_key_id, int dgk_key_id, int 
   if (!pk || !dk || !pk->secret || !dk->secret || l <= 0 || l > 64 || !c_enc || !zeta1 || !zeta2 || !delta_b_out || !out3)
     return fail(ctx, SC_ERR_ARG, "sc_keyholder_step4j_5: bad argument");
   const PaillierKey p = *pk;
-  int rc = sc_dgk_any_zero(ctx, dgk_key_id, c_enc, l + 1, count, delta_b_out); if (rc) return rc;                  // step 4j
+  const DgkKey d = *dk;
+  // step 4j: the l + 1 zero tests of a comparison OR their verdicts into a context-owned accumulator that is zero at rest -- the
+  // launch that encrypts delta_B below reads it, hands it to delta_b_out and resets it (OP_TAKEFLAG): no clearing launch, which as a
+  // runtime fill kernel waited up to 14 ms for a wave slot beside another context's chip-filling launch
+  uint64_t* acc;
+  int rc = zero_kept_flags(ctx, count, &acc); if (rc) return rc;
+  struct Dirty {      // an error between the accumulation and the launch that resets the accumulator must not leave verdicts behind
+    sc_ctx* c; bool armed = true;
+    ~Dirty() { if (armed) drop_zero_kept_flags(c); }
+  } dirty{ctx};
+  rc = modexp_shared_impl(ctx, d.mod_p, d.exp_vp, c_enc, d.nw, nullptr, nullptr, nullptr, ((uint64_t)l + 1) * count, acc, count, true); if (rc) return rc;
   // step 5: three encryptions into the row blocks of one array (no copies of zeta_1 / zeta_2 into a joined plaintext array)
-  // (delta_B's u64 flags are read as two-word little-endian plaintexts where they lie)
   uint32_t* enc = out3;
   if (rho3) { rc = tmp_words(ctx, TMP_S_F, 3 * count * 2 * p.nw, &enc); if (rc) return rc; }
   const size_t blk = (size_t)count * 2 * p.nw;
   rc = sc_paillier_encrypt_raw(ctx, p.mod_n2, p.cst_n, zeta1, p.nw, enc, count); if (rc) return rc;
   rc = sc_paillier_encrypt_raw(ctx, p.mod_n2, p.cst_n, zeta2, p.nw, enc + blk, count); if (rc) return rc;
-  rc = sc_paillier_encrypt_raw(ctx, p.mod_n2, p.cst_n, (const uint32_t*)delta_b_out, 2, enc + 2 * blk, count); if (rc) return rc;
+  {
+    std::string key = "encflag:" + std::to_string(p.mod_n2) + ":" + std::to_string(p.cst_n);
+    auto it = ctx->progs.find(key);
+    if (it == ctx->progs.end()) {
+      Builder bd; const int c = bd.use_const(p.cst_n);
+      bd.emit(OP_TAKEFLAG, 0, 0, 0, 1); bd.mul_const(c);       // delta_B N
+      bd.emit(OP_ADD1); bd.storew(2); bd.end();
+      Prog pr; rc = finalize_prog(ctx, ctx->mods[p.mod_n2], bd, &pr); if (rc) return rc;
+      it = ctx->progs.emplace(key, pr).first;
+    }
+    const int w2 = 2 * p.nw;
+    VmExt ex[3] = {mk_ext(acc, 2, 2), mk_ext(delta_b_out, 2, 2), mk_ext(enc + 2 * blk, w2, w2)};
+    rc = run_vm(ctx, p.mod_n2, it->second, ex, 3, count); if (rc) return rc;
+    dirty.armed = false;
+  }
   if (!rho3) return SC_OK;                                                                                             // unrandomized
   if (flags & SC_STEP_RANDOMIZERS_READY) return sc_modmul(ctx, p.mod_n2, enc, 2 * p.nw, rho3, 2 * p.nw, out3, 3 * count);   // rho^N computed ahead
   return sc_paillier_randomize(ctx, paillier_key_id, enc, rho3, out3, 3 * count);                                    // the 3 .randomize() (:126-128)

@@ -31,6 +31,8 @@ enum VmOpcode : uint32_t {
   OP_CANON = 13,     // ACC = canonical(ACC)
   OP_ADDT = 14,      // ACC += scratch[imm]  (lazy limb-wise add)
   OP_NEG = 15,       // ACC = (n - ACC) mod n, exact limbs
+  OP_TAKEFLAG = 16,  // ACC = v = ext[w1][item] (u64 accumulator of OP_STOREFLAG's OR form); the accumulator is reset to 0 (so that it is
+                     //   zero again for its next use: no clearing pass) and v is written to ext[w2][item] (u64, the caller's copy)
 };
 
 // Opcodes of the pair interpreter k_pvm (arithmetic modulo n^2 with products modulo n, sc_device.h "pair arithmetic").

@@ -70,6 +70,39 @@ def _header(t: torch.Tensor) -> bytes:
     return MAGIC + struct.pack("<BBH", _CODES[t.dtype], t.dim(), 0) + struct.pack(f"<{t.dim()}Q", *t.shape)
 
 
+class _PinnedPool:
+    """Pinned staging buffers for outgoing messages, reused from batch to batch.  Allocating pinned memory is slow (tens of
+    milliseconds for a 0.3 GB message, measured with tools/gpu_wire_probe.py, and it stalls the other sessions' launches too), and
+    torch's caching host allocator does not hand a block back while any stream event on it is pending; a message of the same size is
+    packed once per batch, so a handful of buffers serve a long-running session.  A buffer is free again when nothing refers to the
+    view that was handed out for its previous message (the transport, the receiver's in-place wrapped arrays and its pending
+    host-to-device copies all hold on to that view)."""
+
+    def __init__(self) -> None:
+        self._lock = threading.Lock()
+        self._bufs: list = []          # [pinned tensor, weakref to the last view handed out or None]
+
+    def take(self, nbytes: int) -> tuple[torch.Tensor, np.ndarray]:
+        import weakref
+
+        with self._lock:
+            best = None
+            for entry in self._bufs:
+                if entry[0].numel() >= nbytes and (entry[1] is None or entry[1]() is None):
+                    if best is None or entry[0].numel() < best[0].numel():
+                        best = entry
+            if best is None or best[0].numel() > 2 * nbytes + (1 << 20):
+                cap = (nbytes + (1 << 20) - 1) >> 20 << 20          # whole MiB: chunks of nearly equal sizes share buffers
+                best = [torch.empty(cap, dtype=torch.uint8, pin_memory=True), None]
+                self._bufs.append(best)
+                if len(self._bufs) > 64:                             # never an unbounded cache: drop the free ones
+                    self._bufs = [e for e in self._bufs if e is best or (e[1] is not None and e[1]() is not None)]
+            view = best[0][:nbytes].numpy()
+            best[1] = weakref.ref(view)
+            return best[0][:nbytes], view
+
+
+_pinned_pool = _PinnedPool()
 _copy_streams: dict = {}
 
 
@@ -85,8 +118,8 @@ class PendingMessage:
     """A byte message whose payload copies are still in flight on the copy stream.  `await msg.wait()` yields to the event loop
     until they are done and returns the buffer; the source arrays are kept alive until then."""
 
-    def __init__(self, raw: np.ndarray, event, keep: tuple, started: float) -> None:
-        self._raw, self._event, self._keep, self._t0 = raw, event, keep, started
+    def __init__(self, raw: np.ndarray, event, keep: tuple, started: float, begin=None) -> None:
+        self._raw, self._event, self._keep, self._t0, self._begin = raw, event, keep, started, begin
 
     def done(self) -> bool:
         return self._event is None or self._event.query()
@@ -108,8 +141,9 @@ class PendingMessage:
 
     def _finish(self) -> memoryview:
         if self._keep is not None:
-            STATS["pack_s"] += time.perf_counter() - self._t0        # issue to completion (overlapped with whatever ran meanwhile)
-            self._keep, self._event = None, None
+            # the copies' own duration on the copy stream (they overlap with whatever the compute stream ran meanwhile)
+            STATS["pack_s"] += (self._begin.elapsed_time(self._event) * 1e-3) if self._begin is not None else (time.perf_counter() - self._t0)
+            self._keep, self._event, self._begin = None, None, None
         return memoryview(self._raw)
 
 
@@ -123,18 +157,22 @@ def _pack(tensors: Sequence[torch.Tensor], framed: bool, asynchronous: bool = Fa
     heads = [_header(t) for t in tensors]
     sizes = [len(h) + t.numel() * t.element_size() for h, t in zip(heads, tensors)]
     total = (4 + sum(8 + s for s in sizes)) if framed else sizes[0]
-    pinned = any(t.is_cuda for t in tensors)
-    buf = torch.empty(total, dtype=torch.uint8, pin_memory=pinned)
-    raw = buf.numpy()
+    if on_gpu:
+        buf, raw = _pinned_pool.take(total)
+    else:
+        buf = torch.empty(total, dtype=torch.uint8)
+        raw = buf.numpy()
     off = 0
     if framed:
         raw[0:4] = np.frombuffer(struct.pack("<I", len(tensors)), dtype=np.uint8)
         off = 4
-    side, keep = None, []
+    side, keep, begin = None, [], None
     if on_gpu and asynchronous:
         compute = torch.cuda.current_stream(on_gpu[0].device)
         side = copy_stream(on_gpu[0].device)
         side.wait_stream(compute)                     # the arrays are complete once everything queued so far has run
+        begin = torch.cuda.Event(enable_timing=True)
+        begin.record(side)
     for h, t, s in zip(heads, tensors, sizes):
         if framed:
             raw[off:off + 8] = np.frombuffer(struct.pack("<Q", s), dtype=np.uint8)
@@ -156,9 +194,9 @@ def _pack(tensors: Sequence[torch.Tensor], framed: bool, asynchronous: bool = Fa
     if asynchronous:
         ev = None
         if side is not None:
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=True)
             ev.record(side)
-        return PendingMessage(raw, ev, (buf, tuple(keep)), t0)
+        return PendingMessage(raw, ev, (buf, tuple(keep)), t0, begin)
     STATS["pack_s"] += time.perf_counter() - t0
     return memoryview(raw)
 
