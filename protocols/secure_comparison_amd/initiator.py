@@ -192,7 +192,7 @@ class Initiator:
             draws = draw_alice(count, l, pai, dgk, source, generator)
         z_enc, plain = Initiator.step_1_batch(x_enc, y_enc, l, pai, draws.r, draws.rho_z)
         await comm.send(self.other_party, await wire.outgoing_async(comm, z_enc), msg_id=f"step_1_batch_{tag}")
-        d_enc, beta_enc = wire.incoming(await comm.recv(self.other_party, msg_id=f"step_4b_batch_{tag}"), dev, expect=2)
+        d_enc, beta_enc = wire.incoming(await comm.recv(self.other_party, msg_id=f"step_4b_batch_{tag}"), dev, expect=2, planes_of_one=True)
         d_enc = wire.expect_array(d_enc, (count, nw_d), "[d]")                      # sizes come from this side's l and B,
         beta_enc = wire.expect_array(beta_enc, (l, count, nw_d), "[beta_i]")        # never from the message
         c, _ = Initiator.step_4_batch(d_enc, beta_enc, plain, draws.delta_a, dgk, draws.rhos, draws.permutation, draws.r_alice_dgk)

@@ -16,7 +16,7 @@ for o in d.get("other_configs", []):
     print("  other:", json.dumps(o)[:300])
 ip = d.get("interactive_protocol")
 if ip:
-    print("  interactive", round(ip["value"]), "ratio", round(ip["ratio_to_headline"], 3), "byte transport", round(ip["byte_transport"]["value"]), {k: round(v["value"]) for k, v in ip["byte_transport"].get("pipelined", {}).items()},
+    print("  interactive", round(ip["value"]), "ratio", round(ip["ratio_to_headline"], 3), "byte transport", round(ip["byte_transport"]["value"]), {k: (round(v["value"]), round(v.get("whole_run_value", 0))) for k, v in ip["byte_transport"].get("pipelined", {}).items() if "value" in v},
           "unpipelined", round(ip["byte_transport"].get("single_session_unpipelined", {}).get("value", 0)))
 if "cpu_baseline" in d:
     print("  cpu", d["cpu_baseline"].get("value"), d["cpu_baseline"].get("sample", "")[:120])

@@ -4,11 +4,11 @@
 #   un-profiled bench lines of every BASELINE configuration that fits one GPU.  Output under gpurun_out/$TAG/;
 #   tools/summarize_profiles.py condenses it into profiles/.
 set -o pipefail
-TAG=${1:-r03prof}
+TAG=${1:-r04prof}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-BENCH="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras"
+BENCH="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-other-configs"
 echo "== kernel trace" && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $BENCH > $OUT/stats.log 2>&1 || { tail -5 $OUT/stats.log; exit 1; }
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SALU GRBM_GUI_ACTIVE"; do
   name=pmcf_$(echo $set | tr ' ' '_' | cut -c1-60)
@@ -23,4 +23,7 @@ timeout -k 10 300 python3 bench.py --steps 6 --warmup 2 --batch 131072 --no-extr
 timeout -k 10 300 python3 bench.py --steps 4 --warmup 1 --batch 32768 --l 64 --pbits 3072 --dgk dgk_3072_l64 --no-extras --no-cpu-baseline > $OUT/bench_cfg4share_dgk3072.json 2>> $OUT/bench_other.err || exit 1
 timeout -k 10 300 python3 bench.py --steps 4 --warmup 1 --batch 32768 --l 64 --pbits 3072 --dgk dgk_2048_l64 --no-extras --no-cpu-baseline > $OUT/bench_cfg4share_dgk2048.json 2>> $OUT/bench_other.err || exit 1
 timeout -k 10 300 python3 tools/gpu_kernel_rates.py > $OUT/kernel_rates.txt 2>&1
+echo "== two-shard step dispatches"
+python3 tools/step_dispatches.py $(find $OUT/stats -name "*kernel_trace.csv" | head -1) 2 > $OUT/step_dispatches_two_shards.txt 2>&1
+python3 tools/step_glue.py $(find $OUT/pmcf_FETCH_SIZE -name "*kernel_trace.csv" | head -1) > $OUT/step_glue_single_stream.txt 2>&1
 echo done

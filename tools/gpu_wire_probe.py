@@ -81,7 +81,8 @@ x, y, x_enc, y_enc, _ = bench.synth_inputs(engines[0], l, parts[0][0], parts[0][
 per = B // sessions
 inputs = [(x_enc[i * per:(i + 1) * per].contiguous(), y_enc[i * per:(i + 1) * per].contiguous()) for i in range(sessions)]
 torch.cuda.synchronize()
-reps = 3
+reps = int(os.environ.get("WP_REPS", "5"))
+DONE = []
 results = [None] * sessions
 
 
@@ -96,11 +97,14 @@ def session(i):
                 r, _ = await asyncio.gather(alice.perform_secure_comparison_batch(*inputs[i], engine=engines[i], chunks=chunks), bob.perform_secure_comparison_batch())
                 return r
             results[i] = asyncio.run(go())
-        stream.synchronize()
+            stream.synchronize()
+            DONE.append((time.perf_counter() - T0[0], i))
+
 
 
 for warm in (True, False):
     LOG.clear()
+    DONE.clear()
     T0[0] = time.perf_counter()
     ths = [threading.Thread(target=session, args=(i,)) for i in range(sessions)]
     [t.start() for t in ths]
@@ -109,6 +113,11 @@ for warm in (True, False):
     dt = time.perf_counter() - T0[0]
 print(f"sessions {sessions} chunks {chunks} stagger {stagger * 1e3:.0f} ms: {reps} batches per session in {dt * 1e3:.1f} ms = {B * reps / dt:.0f} comparisons/s "
       f"({dt / reps * 1e3:.1f} ms per batch of {B})")
+done = sorted(DONE)
+print("batch completions (ms, session):", [(round(t * 1e3), i) for t, i in done])
+if len(done) > sessions:
+    n, span = len(done) - sessions, done[-1][0] - done[sessions - 1][0]
+    print(f"steady window: {n} session-batches of {per} in {span * 1e3:.1f} ms = {n * per / span:.0f} comparisons/s")
 tids = sorted({t for t, *_ in LOG})
 for tid in tids[:2]:
     ev = [e for e in LOG if e[0] == tid]
