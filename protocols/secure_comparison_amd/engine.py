@@ -144,6 +144,18 @@ class Engine:
                 raise ValueError(f"{name}: {have} items, expected {rows}")
         return t
 
+    def _result(self, out: torch.Tensor | None, shape: tuple[int, ...], name: str = "out") -> torch.Tensor:
+        """The array a step's last launch stores into: a new device array, or the caller's -- on this device, or in PINNED host
+        memory (mapped into the device's address space: the kernel's stores cross PCIe as posted writes, and no device-to-host copy
+        -- a chip-wide blit kernel on this runtime -- is needed afterwards; wire.reserve hands out such arrays)."""
+        if out is None:
+            return torch.empty(shape, dtype=torch.int32, device=self.device)
+        if not isinstance(out, torch.Tensor) or out.dtype != torch.int32 or tuple(out.shape) != tuple(shape) or not out.is_contiguous():
+            raise ValueError(f"{name}: expected a contiguous int32 array of shape {tuple(shape)}")
+        if out.device != self.device and not (out.device.type == "cpu" and out.is_pinned()):
+            raise ValueError(f"{name}: lives on {out.device}; the engine writes to {self.device} or to pinned host memory")
+        return out
+
     def _host_words(self, x: int, nwords: int):
         arr = int_to_words(x, nwords)
         return arr, arr.ctypes.data_as(C.c_void_p)
@@ -615,7 +627,7 @@ class Engine:
                 raise ValueError(f"{name}: {t.numel()} items, expected {count}")
 
     def initiator_step1(self, key: PaillierKey, l: int, x_enc: torch.Tensor, y_enc: torch.Tensor, r: torch.Tensor,
-                        rho_z: torch.Tensor | None = None, ready: bool = False):
+                        rho_z: torch.Tensor | None = None, ready: bool = False, out: torch.Tensor | None = None):
         """(z_enc, alpha, alpha_tilde, r_small, r_shift): Initiator.step_1 / step_3 for a batch, [[z]] randomized with rho_z^N
         (`ready`: rho_z holds the finished randomizers rho_z^N mod N^2, [B][2nw], computed ahead of time)."""
         count = self._items(x_enc)
@@ -624,7 +636,7 @@ class Engine:
         self._arr(y_enc, "y_enc", count, 2 * nw)
         self._arr(r, "r", count, nw)
         self._arr(rho_z, "rho_z", count, 2 * nw if ready else nw, optional=True)
-        z = self.empty(count, 2 * nw)
+        z = self._result(out, (count, 2 * nw), "z_out")
         alpha = torch.empty((count,), dtype=torch.int64, device=self.device)
         alpha_t, rsmall = torch.empty_like(alpha), torch.empty_like(alpha)
         rshift = self.empty(count, nw)
@@ -635,7 +647,7 @@ class Engine:
         return z, alpha, alpha_t, rsmall, rshift
 
     def keyholder_step2_4b(self, pkey: PaillierKey, dkey: DgkKey, l: int, z_enc: torch.Tensor, r_rand: torch.Tensor | None = None,
-                           ready: bool = False):
+                           ready: bool = False, out: torch.Tensor | None = None):
         """(z, beta, d, zeta_1, zeta_2, [d],[beta_i] as [l+1][B][nw]): KeyHolder.step_2 / 4a / 4b (+ their randomizations)."""
         count = self._items(z_enc)
         nw, nd = pkey.mod_n.nwords, dkey.mod_n.nwords
@@ -644,7 +656,7 @@ class Engine:
         z, zeta1, zeta2 = self.empty(count, nw), self.empty(count, nw), self.empty(count, nw)
         beta = torch.empty((count,), dtype=torch.int64, device=self.device)
         dbit = torch.empty_like(beta)
-        out = torch.empty((l + 1, count, nd), dtype=torch.int32, device=self.device)
+        out = self._result(out, (l + 1, count, nd), "d_beta_out")
         self._sync_stream()
         self._check(self.lib.sc_keyholder_step2_4b(self.ctx, pkey.id, dkey.id, int(l), self._ptr(z_enc), self._ptr(r_rand),
                                                    0 if r_rand is None else r_rand.shape[-1], int(ready), self._ptr(z), self._ptr(beta), self._ptr(dbit),
@@ -653,7 +665,7 @@ class Engine:
 
     def initiator_step4(self, key: DgkKey, l: int, d_enc: torch.Tensor, beta_enc: torch.Tensor, alpha: torch.Tensor, alpha_tilde: torch.Tensor,
                         rsmall: torch.Tensor, delta_a: torch.Tensor, rhos: torch.Tensor | None = None, permutation: torch.Tensor | None = None,
-                        r_rand: torch.Tensor | None = None, want_unblinded: bool = False, ready: bool = False):
+                        r_rand: torch.Tensor | None = None, want_unblinded: bool = False, ready: bool = False, out: torch.Tensor | None = None):
         """(c, c after step 4h or None): Initiator.step_4c .. 4i for a batch; see sc_initiator_step4 (`ready`: r_rand holds h^r)."""
         count = self._items(d_enc)
         nw = key.mod_n.nwords
@@ -666,8 +678,8 @@ class Engine:
             self._arr(permutation, "permutation", dtype=torch.int64)
             if tuple(permutation.shape) != (count, l + 1):
                 raise ValueError(f"permutation: expected int64 [{count}][{l + 1}], got {tuple(permutation.shape)}")
-        out = torch.empty((l + 1, count, nw), dtype=torch.int32, device=self.device)
-        mid = torch.empty_like(out) if (want_unblinded and rhos is not None) else None
+        out = self._result(out, (l + 1, count, nw), "c_out")
+        mid = torch.empty((l + 1, count, nw), dtype=torch.int32, device=self.device) if (want_unblinded and rhos is not None) else None
         self._sync_stream()
         rc = self.lib.sc_initiator_step4(self.ctx, key.id, int(l), self._ptr(d_enc), self._ptr(beta_enc), self._ptr(alpha), self._ptr(alpha_tilde),
                                          self._ptr(rsmall), self._ptr(delta_a), self._ptr(rhos), 0 if rhos is None else rhos.shape[-1],
@@ -697,7 +709,7 @@ class Engine:
         return out
 
     def keyholder_step4j_5(self, pkey: PaillierKey, dkey: DgkKey, l: int, c_enc: torch.Tensor, zeta1: torch.Tensor, zeta2: torch.Tensor,
-                           rho3: torch.Tensor | None = None, ready: bool = False):
+                           rho3: torch.Tensor | None = None, ready: bool = False, out: torch.Tensor | None = None):
         """(delta_B int64 [B], [[zeta_1]] | [[zeta_2]] | [[delta_B]] as [3B][2nw]): KeyHolder.step_4j / step_5 (+ randomizations)."""
         nw, nd = pkey.mod_n.nwords, dkey.mod_n.nwords
         count = self._items(zeta1)
@@ -706,7 +718,7 @@ class Engine:
         self._arr(zeta2, "zeta_2", count, nw)
         self._arr(rho3, "rho3", 3 * count, 2 * nw if ready else nw, optional=True)
         delta_b = torch.empty((count,), dtype=torch.int64, device=self.device)
-        out = self.empty(3 * count, 2 * nw)
+        out = self._result(out, (3 * count, 2 * nw), "out3")
         self._sync_stream()
         self._check(self.lib.sc_keyholder_step4j_5(self.ctx, pkey.id, dkey.id, int(l), self._ptr(c_enc), self._ptr(zeta1), self._ptr(zeta2),
                                                    self._ptr(rho3), int(ready), self._ptr(delta_b), self._ptr(out), count))

@@ -190,18 +190,35 @@ class Initiator:
         nw_p, nw_d = pai.mod_n.nwords, dgk.mod_n.nwords
         if draws is None:
             draws = draw_alice(count, l, pai, dgk, source, generator)
-        z_enc, plain = Initiator.step_1_batch(x_enc, y_enc, l, pai, draws.r, draws.rho_z)
-        await comm.send(self.other_party, await wire.outgoing_async(comm, z_enc), msg_id=f"step_1_batch_{tag}")
-        d_enc, beta_enc = wire.incoming(await comm.recv(self.other_party, msg_id=f"step_4b_batch_{tag}"), dev, expect=2, planes_of_one=True)
-        d_enc = wire.expect_array(d_enc, (count, nw_d), "[d]")                      # sizes come from this side's l and B,
-        beta_enc = wire.expect_array(beta_enc, (l, count, nw_d), "[beta_i]")        # never from the message
-        c, _ = Initiator.step_4_batch(d_enc, beta_enc, plain, draws.delta_a, dgk, draws.rhos, draws.permutation, draws.r_alice_dgk)
+        # a byte transport's messages are laid out in pinned memory up front and written by the steps' own last launches
+        # (wire.reserve: no device-to-host copy afterwards); a device transport gets the arrays themselves
+        msg = wire.reserve(comm, dev, (count, 2 * nw_p))
+        z_enc, plain = Initiator.step_1_batch(x_enc, y_enc, l, pai, draws.r, draws.rho_z, out=None if msg is None else msg.arrays[0])
+        await comm.send(self.other_party, wire.outgoing(comm, z_enc) if msg is None else await msg.finish(), msg_id=f"step_1_batch_{tag}")
+        got = wire.incoming(await comm.recv(self.other_party, msg_id=f"step_4b_batch_{tag}"), dev, expect=None, planes_of_one=True)
+        if len(got) == 1:            # [d] and the planes [beta_i] as ONE array, the way the key holder's launch stored them
+            planes = wire.expect_array(got[0], (l + 1, count, nw_d), "[d], [beta_i]")
+            d_enc, beta_enc = planes[0], planes[1:]
+        elif len(got) == 2:
+            d_enc = wire.expect_array(got[0], (count, nw_d), "[d]")                      # sizes come from this side's l and B,
+            beta_enc = wire.expect_array(got[1], (l, count, nw_d), "[beta_i]")           # never from the message
+        else:
+            raise ValueError(f"batch message carries {len(got)} arrays, expected [d] and [beta_i]")
         if draws.permutation is not None and not bool(Initiator.permutation_is_valid(draws.permutation)):
-            raise ValueError("permutation: a row is not a permutation of the l + 1 positions")   # before anything is sent
-        await comm.send(self.other_party, await wire.outgoing_async(comm, c), msg_id=f"step_4i_batch_{tag}")
-        zeta_1, zeta_2, delta_b_enc = wire.incoming(await comm.recv(self.other_party, msg_id=f"step_5_batch_{tag}"), dev, expect=3)
-        zeta_1, zeta_2, delta_b_enc = (wire.expect_array(t, (count, 2 * nw_p), name) for t, name in
-                                       ((zeta_1, "[[zeta_1]]"), (zeta_2, "[[zeta_2]]"), (delta_b_enc, "[[delta_B]]")))
+            raise ValueError("permutation: a row is not a permutation of the l + 1 positions")   # before anything is computed or sent
+        msg = wire.reserve(comm, dev, (l + 1, count, nw_d))
+        c, _ = Initiator.step_4_batch(d_enc, beta_enc, plain, draws.delta_a, dgk, draws.rhos, draws.permutation, draws.r_alice_dgk,
+                                      out=None if msg is None else msg.arrays[0])
+        await comm.send(self.other_party, wire.outgoing(comm, c) if msg is None else await msg.finish(), msg_id=f"step_4i_batch_{tag}")
+        got = wire.incoming(await comm.recv(self.other_party, msg_id=f"step_5_batch_{tag}"), dev, expect=None)
+        if len(got) == 1:            # [[zeta_1]] | [[zeta_2]] | [[delta_B]] as the row blocks of one array
+            three = wire.expect_array(got[0], (3, count, 2 * nw_p), "[[zeta_1]], [[zeta_2]], [[delta_B]]")
+            zeta_1, zeta_2, delta_b_enc = three[0], three[1], three[2]
+        elif len(got) == 3:
+            zeta_1, zeta_2, delta_b_enc = (wire.expect_array(t, (count, 2 * nw_p), name) for t, name in
+                                           ((got[0], "[[zeta_1]]"), (got[1], "[[zeta_2]]"), (got[2], "[[delta_B]]")))
+        else:
+            raise ValueError(f"batch message carries {len(got)} arrays, expected three ciphertext blocks")
         return Initiator.step_6_7_batch(draws.delta_a, delta_b_enc, zeta_1, zeta_2, plain, l, pai, out)   # one inversion pass
 
     async def receive_encryption_schemes(self, session_id: int = 1) -> None:
@@ -324,27 +341,29 @@ class Initiator:
     # ------------------------------------------------------------------ batched steps (device arrays): one library call each
     @staticmethod
     def step_1_batch(x_enc: torch.Tensor, y_enc: torch.Tensor, l: int, scheme_paillier: Paillier, r: torch.Tensor,
-                     rho_z: torch.Tensor | None = None, randomizers_ready: bool = False) -> tuple[torch.Tensor, AlicePlain]:
+                     rho_z: torch.Tensor | None = None, randomizers_ready: bool = False,
+                     out: torch.Tensor | None = None) -> tuple[torch.Tensor, AlicePlain]:
         """B times step 1 + step 3 + the plaintext side of 4c/4e/7 (sc_initiator_step1).  x_enc, y_enc: [B][2nw]; r: [B][nw]
         (injected); rho_z: [B][nw] = the `.randomize()` of [[z]] (SC/initiator.py:109) fused in -- or, with
         `randomizers_ready`, the finished randomizers rho_z^N mod N^2 ([B][2nw]) computed ahead of time."""
         n = scheme_paillier.public_key.n
         assert (1 << (l + 2)) < n // 2
         z, alpha, alpha_tilde, r_small, r_shift = scheme_paillier.engine.initiator_step1(scheme_paillier.key, l, x_enc, y_enc, r, rho_z,
-                                                                                         randomizers_ready)
+                                                                                         randomizers_ready, out)
         return z, AlicePlain(r, alpha, alpha_tilde, r_small, r_shift)
 
     @staticmethod
     def step_4_batch(d_enc: torch.Tensor, beta_is_enc: torch.Tensor, plain: AlicePlain, delta_a: torch.Tensor, scheme_dgk: DGK,
                      rhos: torch.Tensor, permutation: torch.Tensor | None = None, randomizer_exponents: torch.Tensor | None = None,
-                     want_unblinded: bool = False, randomizers_ready: bool = False) -> tuple[torch.Tensor, torch.Tensor | None]:
+                     want_unblinded: bool = False, randomizers_ready: bool = False,
+                     out: torch.Tensor | None = None) -> tuple[torch.Tensor, torch.Tensor | None]:
         """Steps 4c .. 4i for B comparisons in ONE library call (sc_initiator_step4): the inversion pass over [d], [beta_i], the
         fused steps 4c-4h, the blinding c_i^rho_i, the re-randomization * h^r_i (`randomizer_exponents`) and the shuffle.
         With `randomizers_ready`, `randomizer_exponents` holds the finished h^r_i ([l+1][B][nw]) instead of the exponents.
         Returns ([c_i] as sent: [l+1][B][nw], and the unblinded vector of step 4h when `want_unblinded`)."""
         l = beta_is_enc.shape[0]
         return scheme_dgk.engine.initiator_step4(scheme_dgk.key, l, d_enc, beta_is_enc, plain.alpha, plain.alpha_tilde, plain.r_small, delta_a,
-                                                 rhos, permutation, randomizer_exponents, want_unblinded, randomizers_ready)
+                                                 rhos, permutation, randomizer_exponents, want_unblinded, randomizers_ready, out)
 
     @staticmethod
     def step_4c_to_4h_batch(d_enc: torch.Tensor, beta_is_enc: torch.Tensor, plain: AlicePlain, delta_a: torch.Tensor,

@@ -158,13 +158,18 @@ class KeyHolder:
         z_enc = wire.expect_array(z_enc, (count, 2 * pai.mod_n.nwords), "[[z]]")
         if draws is None:
             draws = draw_bob(count, l, pai, dgk, source, generator)
-        plain, d_enc, beta_enc = KeyHolder.step_2_4b_batch(z_enc, l, pai, dgk, draws.r_bob_dgk)
-        await comm.send(self.other_party, await wire.outgoing_async(comm, d_enc, beta_enc), msg_id=f"step_4b_batch_{tag}")
+        # (byte transports: the messages are written in place by the steps' last launches, see Initiator._batch_session)
+        msg = wire.reserve(comm, dev, (l + 1, count, dgk.mod_n.nwords))
+        plain, d_enc, beta_enc = KeyHolder.step_2_4b_batch(z_enc, l, pai, dgk, draws.r_bob_dgk, out=None if msg is None else msg.arrays[0])
+        await comm.send(self.other_party, wire.outgoing(comm, d_enc, beta_enc) if msg is None else await msg.finish(), msg_id=f"step_4b_batch_{tag}")
         (c_enc,) = wire.incoming(await comm.recv(self.other_party, msg_id=f"step_4i_batch_{tag}"), dev, expect=1)
         c_enc = wire.expect_array(c_enc, (l + 1, count, dgk.mod_n.nwords), "[c_i]")
+        msg = wire.reserve(comm, dev, (3, count, 2 * pai.mod_n.nwords))
         _, zeta_1_enc, zeta_2_enc, delta_b_enc = KeyHolder.step_4j_5_batch(
-            c_enc, plain, pai, dgk, cat_rows([draws.rho_zeta_1, draws.rho_zeta_2, draws.rho_delta_b]))
-        await comm.send(self.other_party, await wire.outgoing_async(comm, zeta_1_enc, zeta_2_enc, delta_b_enc), msg_id=f"step_5_batch_{tag}")
+            c_enc, plain, pai, dgk, cat_rows([draws.rho_zeta_1, draws.rho_zeta_2, draws.rho_delta_b]),
+            out=None if msg is None else msg.arrays[0].reshape(3 * count, 2 * pai.mod_n.nwords))
+        await comm.send(self.other_party, wire.outgoing(comm, zeta_1_enc, zeta_2_enc, delta_b_enc) if msg is None else await msg.finish(),
+                        msg_id=f"step_5_batch_{tag}")
 
     async def make_and_send_encryption_schemes(self, session_id: int = 1, key_length_paillier: int = 2048,
                                                v_bits_dgk: int = 160, n_bits_dgk: int = 2048) -> None:
@@ -245,7 +250,8 @@ class KeyHolder:
 
     @staticmethod
     def step_2_4b_batch(z_enc: torch.Tensor, l: int, scheme_paillier: Paillier, scheme_dgk: DGK,
-                        randomizer_exponents: torch.Tensor | None = None, randomizers_ready: bool = False) -> tuple[BobPlain, torch.Tensor, torch.Tensor]:
+                        randomizer_exponents: torch.Tensor | None = None, randomizers_ready: bool = False,
+                        out: torch.Tensor | None = None) -> tuple[BobPlain, torch.Tensor, torch.Tensor]:
         """Steps 2, 4a, 4b (and, with `randomizer_exponents` [l+1][B][ew], the l + 1 `.randomize()` of SC/keyholder.py:106-108) in ONE
         library call (sc_keyholder_step2_4b).  Returns (plain, [d] as [B][nw], [beta_i] as [l][B][nw]) -- the latter two are the
         planes of one array, so the initiator's inversion pass takes them without a copy."""
@@ -253,18 +259,19 @@ class KeyHolder:
         count = z_enc.shape[0]
         rr = None if randomizer_exponents is None else randomizer_exponents.reshape((l + 1) * count, -1)
         z, beta, d, zeta_1, zeta_2, enc = scheme_paillier.engine.keyholder_step2_4b(scheme_paillier.key, scheme_dgk.key, l, z_enc, rr,
-                                                                                    randomizers_ready)
+                                                                                    randomizers_ready, out)
         return BobPlain(z, beta, d, zeta_1, zeta_2), enc[0], enc[1:]
 
     @staticmethod
     def step_4j_5_batch(c_is_enc: torch.Tensor, plain: BobPlain, scheme_paillier: Paillier, scheme_dgk: DGK,
-                        rho3: torch.Tensor | None = None, randomizers_ready: bool = False) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+                        rho3: torch.Tensor | None = None, randomizers_ready: bool = False,
+                        out: torch.Tensor | None = None) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
         """Steps 4j and 5 (and, with rho3 [3B][nw] = the bases for [[zeta_1]], [[zeta_2]], [[delta_B]] in that order, the three
         `.randomize()` of SC/keyholder.py:126-128) in ONE library call (sc_keyholder_step4j_5).
         Returns (delta_B [B] u64, [[zeta_1]], [[zeta_2]], [[delta_B]])."""
         l, count = c_is_enc.shape[0] - 1, c_is_enc.shape[1]
         delta_b, enc = scheme_paillier.engine.keyholder_step4j_5(scheme_paillier.key, scheme_dgk.key, l, c_is_enc, plain.zeta_1, plain.zeta_2, rho3,
-                                                                 randomizers_ready)
+                                                                 randomizers_ready, out)
         return delta_b, enc[:count], enc[count:2 * count], enc[2 * count:]
 
     @staticmethod

@@ -12,9 +12,20 @@ vector at B = 65536), so a batch travels in one of two forms, chosen by what the
   `memoryview`:
 
       message  = count u32 | { length u64 | array }*            (pack_many)
-      array    = magic "SCB1" | dtype code u8 | ndim u8 | reserved u16 | dims (ndim x u64) | payload (little-endian words)
+      array    = magic "SCB1" | dtype code u8 | ndim u8 | pad u16 | dims (ndim x u64) | pad bytes | payload (little-endian words)
+
+  (`pad` is 0 in packed messages; a message whose payloads the producing KERNELS write -- `reserve`, below -- pads so that every
+  payload starts on a 256-byte boundary of the pinned buffer.)
 
   The receiver wraps the payload in place (`torch.frombuffer`) and issues one host-to-device copy per array.
+
+**No device-to-host copy at all (round 4).**  On this runtime every device-to-host `hipMemcpyAsync` is executed by a blit kernel
+(`__amd_rocclr_copyBuffer`, 4096 waves for a 0.3 GB message; host-to-device copies use an SDMA engine -- `tools/gpu_copy_probe.py`):
+beside another session's chip-filling launches it waits for wave slots, and once running it holds them for the ~5 ms the bytes
+take to cross PCIe.  So the sender does not copy: `reserve` lays the message out in a pooled pinned buffer up front and hands back
+its payload regions as arrays; the step's LAST launch stores its results straight into them (pinned host memory is mapped into
+the device's address space; the stores are posted PCIe writes spread over the launch), and `Reserved.finish` only waits for the
+compute stream's event.
 
 **Pipelining (round 4).**  A byte message of a batch is ~0.5 GB; copying it out of HBM takes ~10 ms during which a single
 session's GPU would idle.  `outgoing_async` therefore issues the device-to-host copies on a COPY STREAM of its own (after an event
@@ -202,6 +213,62 @@ def _pack(tensors: Sequence[torch.Tensor], framed: bool, asynchronous: bool = Fa
     return memoryview(raw)
 
 
+class Reserved:
+    """A byte message under construction whose payloads are written by the producing kernels themselves (see the module text):
+    `arrays[i]` is the i-th payload as a pinned host array of the requested shape -- pass it as the step's output array --, and
+    `await finish()` yields the finished message once everything queued on the current stream has run."""
+
+    ALIGN = 256
+
+    def __init__(self, device, shapes: Sequence[tuple[int, ...]], dtype: torch.dtype = torch.int32) -> None:
+        item = torch.empty((), dtype=dtype).element_size()
+        code = _CODES[dtype]
+        off, plan = 4, []
+        for shape in shapes:
+            if len(shape) > MAX_NDIM:
+                raise ValueError(f"at most {MAX_NDIM} dimensions")
+            n = 1
+            for d in shape:
+                n *= int(d)
+            head = 8 + 8 * len(shape)
+            start = off + 8 + head                               # where the payload would begin without padding
+            pad = (-start) % self.ALIGN
+            plan.append((off, head, pad, n * item, tuple(int(d) for d in shape)))
+            off = start + pad + n * item
+        self._device = torch.device(device)
+        self._buf, self._raw = _pinned_pool.take(off)
+        raw = self._raw
+        raw[0:4] = np.frombuffer(struct.pack("<I", len(plan)), dtype=np.uint8)
+        self.arrays = []
+        for o, head, pad, nbytes, shape in plan:
+            raw[o:o + 8] = np.frombuffer(struct.pack("<Q", head + pad + nbytes), dtype=np.uint8)
+            raw[o + 8:o + 8 + head] = np.frombuffer(MAGIC + struct.pack("<BBH", code, len(shape), pad) + struct.pack(f"<{len(shape)}Q", *shape), dtype=np.uint8)
+            raw[o + 8 + head:o + 8 + head + pad] = 0
+            p0 = o + 8 + head + pad
+            self.arrays.append(self._buf[p0:p0 + nbytes].view(dtype).reshape(shape))
+        STATS["bytes"] += off
+
+    async def finish(self) -> memoryview:
+        import asyncio
+
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self._device))
+        spins = 0
+        while not ev.query():
+            spins += 1
+            await asyncio.sleep(0 if spins < 200 else 0.0001)
+        self.arrays = None
+        return memoryview(self._raw)
+
+
+def reserve(communicator: Any, device, *shapes: tuple[int, ...]) -> "Reserved | None":
+    """A message of int32 arrays of these shapes whose payloads the step's kernels will write in place -- or None when the transport
+    carries device arrays (then the step allocates device outputs and `outgoing` hands them over) or the arrays live on the CPU."""
+    if carries_device_arrays(communicator) or torch.device(device).type != "cuda":
+        return None
+    return Reserved(device, shapes)
+
+
 def pack_tensor(t: torch.Tensor) -> memoryview:
     return _pack([t], framed=False)
 
@@ -257,13 +324,13 @@ def plan_of(message: Any) -> list[int] | None:
     return sizes
 
 
-def incoming(message: Any, device: torch.device | str, expect: int, planes_of_one: bool = False) -> list[torch.Tensor]:
-    """The arrays of a received message (either form), on `device`; exactly `expect` of them.
+def incoming(message: Any, device: torch.device | str, expect: int | None, planes_of_one: bool = False) -> list[torch.Tensor]:
+    """The arrays of a received message (either form), on `device`; exactly `expect` of them (None: the caller checks the count).
     planes_of_one: the arrays are [B][w] followed by [k][B][w] of the same dtype -- [d] and the planes [beta_i] -- and the caller
     wants them as the consecutive planes of ONE device array (what the initiator's inversion pass takes without a joining copy:
     a 0.3 GB device-to-device copy per batch otherwise, done by a runtime blit kernel that queues behind other sessions' launches)."""
     if isinstance(message, DeviceArrays):
-        if len(message.arrays) != expect:
+        if expect is not None and len(message.arrays) != expect:
             raise ValueError(f"batch message carries {len(message.arrays)} arrays, expected {expect}")
         dev = torch.device(device)
         for t in message.arrays:
@@ -300,24 +367,24 @@ def unpack_tensor(buf: Any, device: torch.device | str = "cpu", into: torch.Tens
     mv = _as_view(buf)
     if len(mv) < 8 or bytes(mv[:4]) != MAGIC:
         raise ValueError("not a secure-comparison batch message")
-    code, ndim, _ = struct.unpack_from("<BBH", mv, 4)
+    code, ndim, pad = struct.unpack_from("<BBH", mv, 4)
     if code not in _DTYPES:
         raise ValueError(f"unknown dtype code {code} in batch message")
-    if ndim > MAX_NDIM or len(mv) < 8 + 8 * ndim:
+    if ndim > MAX_NDIM or pad > 4096 or len(mv) < 8 + 8 * ndim + pad:
         raise ValueError("malformed batch message header")
     shape = struct.unpack_from(f"<{ndim}Q", mv, 8)
     tdt, ndt = _DTYPES[code]
     count = 1
     for d in shape:
         count *= d
-    if count * ndt.itemsize != len(mv) - 8 - 8 * ndim:
-        raise ValueError(f"batch message announces shape {tuple(shape)} but carries {len(mv) - 8 - 8 * ndim} payload bytes")
+    if count * ndt.itemsize != len(mv) - 8 - 8 * ndim - pad:
+        raise ValueError(f"batch message announces shape {tuple(shape)} but carries {len(mv) - 8 - 8 * ndim - pad} payload bytes")
     if into is not None and (into.dtype != tdt or into.numel() != count or not into.is_contiguous()):
         raise ValueError(f"batch message announces {count} elements of {tdt}, the receiving array holds {into.numel()} of {into.dtype}")
     if count == 0:
         out = torch.empty(tuple(shape), dtype=tdt, device=device) if into is None else into.reshape(tuple(shape))
     else:
-        payload = mv[8 + 8 * ndim:]
+        payload = mv[8 + 8 * ndim + pad:]
         import warnings
 
         with warnings.catch_warnings():      # immutable `bytes` from a socket: wrapped all the same, and only ever read
@@ -365,8 +432,8 @@ def _peek_shape(mv: memoryview) -> tuple[int, tuple[int, ...]]:
     """(dtype code, shape) announced by an array message, after the same header checks unpack_tensor makes."""
     if len(mv) < 8 or bytes(mv[:4]) != MAGIC:
         raise ValueError("not a secure-comparison batch message")
-    code, ndim, _ = struct.unpack_from("<BBH", mv, 4)
-    if code not in _DTYPES or ndim > MAX_NDIM or len(mv) < 8 + 8 * ndim:
+    code, ndim, pad = struct.unpack_from("<BBH", mv, 4)
+    if code not in _DTYPES or ndim > MAX_NDIM or pad > 4096 or len(mv) < 8 + 8 * ndim + pad:
         raise ValueError("malformed batch message header")
     return code, tuple(struct.unpack_from(f"<{ndim}Q", mv, 8))
 

@@ -136,7 +136,7 @@ class OracleEngine:
         planes, count, nw = c.shape
         return self.modexp_shared_isone_any(key.mod_p, c.reshape(planes * count, nw), key.sk.v_p, count)
 
-    def initiator_step1(self, key, l, x_enc, y_enc, r, rho_z=None, ready=False):
+    def initiator_step1(self, key, l, x_enc, y_enc, r, rho_z=None, ready=False, out=None):
         n, n2 = key.mod_n.n, key.mod_n2.n
         m1, alpha, alpha_t, rsmall, rshift = self.plain_alice(r, n, l)
         z = self.modmul(key.mod_n2, self.modmul(key.mod_n2, y_enc, self.modinv(key.mod_n2, x_enc)), self.paillier_encrypt(key, m1))
@@ -144,7 +144,7 @@ class OracleEngine:
             z = self.modmul(key.mod_n2, z, rho_z) if ready else self.paillier_randomize(key, z, rho_z)
         return z, alpha, alpha_t, rsmall, rshift
 
-    def keyholder_step2_4b(self, pkey, dkey, l, z_enc, r_rand=None, ready=False):
+    def keyholder_step2_4b(self, pkey, dkey, l, z_enc, r_rand=None, ready=False, out=None):
         count = z_enc.shape[0]
         z = self.paillier_decrypt(pkey, z_enc)
         beta, dbit, zeta1, zeta2 = self.plain_bob(z, pkey.mod_n.n, l)
@@ -184,7 +184,7 @@ class OracleEngine:
         return flat.reshape(lp1, count, nw)
 
     def initiator_step4(self, key, l, d_enc, beta_enc, alpha, alpha_tilde, rsmall, delta_a, rhos=None, permutation=None, r_rand=None,
-                        want_unblinded=False, ready=False):
+                        want_unblinded=False, ready=False, out=None):
         count, nw = d_enc.shape
         inv = self.modinv(key.mod_n, torch.cat([d_enc.reshape(1, count, nw), beta_enc]).reshape((l + 1) * count, nw))
         c_h = self.dgk_step4(key.mod_n, key.sk.g, o.mod_inv(key.sk.g, key.mod_n.n), l, beta_enc, inv[count:].reshape(l, count, nw), d_enc,
@@ -193,7 +193,7 @@ class OracleEngine:
             return c_h, None
         return self.initiator_step4i(key, l, c_h, rhos, permutation, r_rand, ready), (c_h if want_unblinded else None)
 
-    def keyholder_step4j_5(self, pkey, dkey, l, c_enc, zeta1, zeta2, rho3=None, ready=False):
+    def keyholder_step4j_5(self, pkey, dkey, l, c_enc, zeta1, zeta2, rho3=None, ready=False, out=None):
         count = zeta1.shape[0]
         delta_b = self.dgk_any_zero(dkey, c_enc.reshape(l + 1, count, -1))
         db = self.upload([int(v) for v in delta_b.tolist()], zeta1.shape[-1])

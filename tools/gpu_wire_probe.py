@@ -60,6 +60,18 @@ def _pack(tensors, framed, asynchronous=False):
 
 
 wire._pack = _pack
+_orig_finish = wire.Reserved.finish
+
+
+async def _finish(self):
+    t = time.perf_counter()
+    try:
+        return await _orig_finish(self)
+    finally:
+        LOG.append((threading.get_ident(), "message written by the step's launches (wait)", t - T0[0], time.perf_counter() - T0[0]))
+
+
+wire.Reserved.finish = _finish
 
 keys = json.load(open(bench.KEYS))
 pj, dj = keys["paillier_2048"], keys["dgk_2048_l32"]
