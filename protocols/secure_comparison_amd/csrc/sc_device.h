@@ -342,6 +342,73 @@ struct Grp {
     neg_quot_init(q);
     mont<0, false, true, false, true>(x1, a2_lds, x1, q, nullptr, q);   // x1 <- (2 x0 x1 + R - q + q' n) / R + n - 1
   }
+  // The same pair squaring with its two passes INTERLEAVED limb step by limb step (small-batch configurations, L <= 9).  A small
+  // batch is one dependent chain of ~2400 pair squarings per item on a chip with waves to spare: what a squaring costs there is the
+  // LATENCY of its chain of limb steps (multiply-add -> quotient digit -> broadcast -> multiply-add -> carry -> hand-over, ~55
+  // cycles a step), not its instruction count.  Pass 2 needs pass 1 only through the start value R - q, and digit d of q is born in
+  // step d of pass 1 while position d of pass 2's running sum is consumed in ITS step d: so pass 2 runs in the shadow of pass 1,
+  // one step behind inside the same loop iteration, with the complemented digit added to the bottom lane's lowest column at the
+  // moment it is produced (the broadcast already brought it there) instead of to the start value.  The represented integer, the
+  // quotient digits and the results are those of pair_sqr bit for bit; the two chains give the scheduler two independent
+  // instruction streams per wave.
+  __device__ __forceinline__ void pair_sqr_il(uint32_t (&x0)[L], uint32_t (&x1)[L], const uint32_t* a_lds, const uint32_t* a2_lds) const {
+    static_assert(G > 1 && L <= 9, "interleaved pair squaring: multi-lane small-batch configurations");
+    uint64_t T1[L], T2[L];
+#pragma unroll
+    for (int i = 0; i < L; i++) { T1[i] = 0ull; T2[i] = 0ull; }
+    uint32_t first = (j == 0) ? 1u : 0u;                   // the "+ 1" of R - q = complement + 1, at digit 0
+#pragma unroll 1
+    for (int k = 0; k < G; k++) {
+#pragma unroll
+      for (int l = 0; l < L; l++) {
+        const uint32_t ai = a_lds[k * L + l], ai2 = a2_lds[k * L + l];
+        // ---- pass 1: t = (x0^2 + q n) / R, upper triangle doubled (mont<3>)
+        T1[(l + l) % L] += (uint64_t)ai * x0[l];
+#pragma unroll
+        for (int c = l + 1; c < L; c++) T1[(l + c) % L] += (uint64_t)ai2 * x0[c];
+        const uint32_t q1 = bcast0<G>(NEG1 ? (uint32_t)T1[l] : (uint32_t)T1[l] * n0inv) & lmask_v;
+#pragma unroll
+        for (int c = 0; c < L; c++) T1[(l + c) % L] += (uint64_t)q1 * n[c];
+        const uint64_t t1 = T1[l];
+        T1[(l + 1) % L] += t1 >> W;
+        T1[l] = (uint64_t)(from_above_raw((uint32_t)t1) & lmask_v);
+        // ---- pass 2: (2 x0 x1 + R - q + q' n) / R, digit d of R - q added where position d is about to be consumed
+        T2[l] += (uint64_t)(((LMASK - q1) + first) & ~notBot);       // bottom lane only (notBot is 0 there)
+        first = 0u;
+#pragma unroll
+        for (int c = 0; c < L; c++) T2[(l + c) % L] += (uint64_t)ai2 * x1[c];
+        const uint32_t q2 = bcast0<G>(NEG1 ? (uint32_t)T2[l] : (uint32_t)T2[l] * n0inv) & lmask_v;
+#pragma unroll
+        for (int c = 0; c < L; c++) T2[(l + c) % L] += (uint64_t)q2 * n[c];
+        const uint64_t t2 = T2[l];
+        T2[(l + 1) % L] += t2 >> W;
+        T2[l] = (uint64_t)(from_above_raw((uint32_t)t2) & lmask_v);
+      }
+    }
+    // the two final carry passes of mont(): plain for t, with n - 1 added for the n-part (the correction for the start value R - q)
+    uint64_t c1 = 0ull, c2 = (uint64_t)(n[0] - ((j == 0) ? 1u : 0u));
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+      const uint64_t v1 = T1[l] + c1;
+      x0[l] = (uint32_t)v1 & LMASK;
+      c1 = v1 >> W;
+      const uint64_t v2 = T2[l] + c2 + ((l > 0) ? (uint64_t)n[l] : 0ull);
+      x1[l] = (uint32_t)v2 & LMASK;
+      c2 = v2 >> W;
+    }
+    {
+      const uint32_t clo = from_below((uint32_t)c1), chi = from_below((uint32_t)(c1 >> 32));
+      const uint64_t v = (uint64_t)x0[0] + (((uint64_t)chi << 32) | clo);
+      x0[0] = (uint32_t)v & LMASK;
+      x0[1] += (uint32_t)(v >> W);
+    }
+    {
+      const uint32_t clo = from_below((uint32_t)c2), chi = from_below((uint32_t)(c2 >> 32));
+      const uint64_t v = (uint64_t)x1[0] + (((uint64_t)chi << 32) | clo);
+      x1[0] = (uint32_t)v & LMASK;
+      x1[1] += (uint32_t)(v >> W);
+    }
+  }
   // (x0, x1) <- (x0, x1) * (y0, y1) ;  y0_lds / y1_lds hold the second operand
   __device__ __forceinline__ void pair_mul(uint32_t (&x0)[L], uint32_t (&x1)[L], const uint32_t* y0_lds, const uint32_t* y1_lds) const {
     uint32_t t[L], q[L];

@@ -7,6 +7,9 @@ namespace sc {
 #ifndef SC_VM_WAVES
 #define SC_VM_WAVES 2     // waves per SIMD the single-modulus interpreter is compiled for (L <= 18 configurations)
 #endif
+#ifndef SC_PAIR_SQR_INTERLEAVED
+#define SC_PAIR_SQR_INTERLEAVED 1   // measurement switch: 0 = the two passes of a small-batch pair squaring one after the other
+#endif
 #ifndef SC_PVM_WAVES
 #define SC_PVM_WAVES 2    // same for the pair interpreter
 #endif
@@ -411,6 +414,8 @@ __global__ void __launch_bounds__(64, ((G == 16 && L > 9) ? 1 : SC_PVM_WAVES)) k
             gp.stage(my_a, x0);
             gp.stage_doubled(my_a2, x0);
             SC_WAVE_SYNC();
+            // small-batch configurations: the two passes interleaved -- the chain's latency is what a squaring costs there
+            if constexpr (L <= 9 && SC_PAIR_SQR_INTERLEAVED) gp.pair_sqr_il(x0, x1, my_a, my_a2); else
             gp.pair_sqr(x0, x1, my_a, my_a2);
           }
           break;
