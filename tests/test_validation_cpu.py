@@ -236,3 +236,41 @@ def test_zero_copy_row_joins():
     x = cat_rows([b[:2], b[2:4], b[4:]])
     assert x.data_ptr() == b.data_ptr() and torch.equal(x, b)
     assert cat_rows([b[:3], b[3:].to(torch.int64)]).dtype == torch.int64      # mixed dtypes: plain torch.cat semantics
+
+
+def test_kernel_written_message_layout_and_padding(monkeypatch):
+    """wire.Reserved lays a byte message out up front (payloads on 256-byte boundaries of the buffer, the padding announced in the
+    array header) so that the producing kernels can write it in place; the receiver parses it like a packed message, and a header
+    whose padding does not fit the bytes that arrived is refused.  (On the GPU the buffer is pinned memory from the pool; here a
+    plain one stands in -- the layout code is the same.)"""
+    import struct
+
+    from protocols.secure_comparison_amd import wire
+
+    class PlainPool:
+        def take(self, nbytes):
+            buf = torch.zeros(nbytes + 64, dtype=torch.uint8)[:nbytes]
+            return buf, buf.numpy()
+
+    monkeypatch.setattr(wire, "_pinned_pool", PlainPool())
+    shapes = [(5, 7), (3, 5, 7), (0, 4)]
+    msg = wire.Reserved("cpu", shapes)
+    for i, a in enumerate(msg.arrays):
+        assert tuple(a.shape) == shapes[i] and a.dtype == torch.int32
+        assert (a.data_ptr() - msg._buf.data_ptr()) % wire.Reserved.ALIGN == 0 or a.numel() == 0
+        a.copy_(torch.arange(a.numel(), dtype=torch.int32).reshape(shapes[i]) + 1000 * i)
+    raw = bytes(memoryview(msg._raw))
+    got = wire.unpack_many(raw, "cpu", expect=3)
+    assert [tuple(t.shape) for t in got] == shapes and got[1][2, 4, 6].item() == 1000 + 3 * 5 * 7 - 1
+    joined = wire.unpack_many(bytes(memoryview(wire.Reserved("cpu", [(5, 7), (3, 5, 7)])._raw)), "cpu", expect=2, planes_of_one=True)
+    assert joined[1].data_ptr() == joined[0].data_ptr() + 5 * 7 * 4          # [d] and the planes [beta_i] as one array
+    # a padding that runs past the message, or an absurd one, is refused
+    one = wire.Reserved("cpu", [(2, 2)])
+    mv = bytearray(memoryview(one._raw))
+    (ln,) = struct.unpack_from("<Q", mv, 4)
+    struct.pack_into("<H", mv, 4 + 8 + 6, 5000)
+    with pytest.raises(ValueError):
+        wire.unpack_many(bytes(mv), "cpu")
+    struct.pack_into("<H", mv, 4 + 8 + 6, 3)                                   # another padding: the payload size no longer matches
+    with pytest.raises(ValueError):
+        wire.unpack_many(bytes(mv), "cpu")
