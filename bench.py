@@ -836,72 +836,95 @@ def measure(args, torch, dist, rank: int, world: int, full: bool, rt=None):
             except Exception as exc:  # pragma: no cover
                 out["cpu_baseline"] = {"value": None, "unit": "comparisons/s", "cores": cores, "kind": "port", "sample": f"failed: {exc}"}
         if not args.no_extras and world == 1:
-            # ---- how much of `value` hangs on the 6 GB window-20 table: the same step with smaller fixed-base windows
-            sens = {str(args.fb_window): {"value": value, "table_bytes": table_bytes, "table_build_s": table_build_s}}
-            for w in (8, 16, 20):
-                if w == args.fb_window:
-                    continue
-                ps_w, bs_w, tb_w = build_parties(w)
-                step_w, close_w = make_step(ps_w)
-                step_w()
-                dt_w, _ = timed(step_w, 2)
-                close_w()
-                sens[str(w)] = {"value": B * 2 / dt_w, "table_bytes": tb_w, "table_build_s": bs_w}
-                del ps_w, step_w, close_w
-                rt.empty_cache()
-            out["window_sensitivity"] = sens
-            # ---- the real two-party batch protocol (reported, never `value`): Initiator / KeyHolder
-            # .perform_secure_comparison_batch with draws=None over the in-memory transport -- every random input drawn on the
-            # device by the library's CSPRNG inside the timed region, messages handed over as device arrays (or, second figure,
-            # serialized through one pinned host buffer per message as a real transport would need)
-            def one_more_party():      # a further session's context and scheme objects (same keys, the first context's tables)
-                e_x = rt.new_engine()
-                e_x.set_latency_mode(args.latency_mode)
-                e_x.set_onelane_mode(args.onelane_mode)
-                bob_px = Paillier(p * q, p, q, engine=e_x, use_crt=use_crt)
-                bob_dx = DGK(H("p") * H("q"), H("g"), H("h"), H("u"), dj["t"], H("p"), H("q"), H("v_p"), H("v_q"), engine=e_x,
-                             randomizer_bits=args.rbits, fixed_base_window=args.fb_window, use_crt=use_crt)
-                alice_dx = bob_dx.public_copy()
-                bob_dx.share_tables_from(parties[0].bob_dgk)
-                alice_dx.share_tables_from(parties[0].alice_dgk)
-                alice_dx.prepare(), bob_dx.prepare()
-                alice_px = bob_px.public_copy()
-                _ = bob_px.key, alice_px.key
-                return PartySet(alice_px, alice_dx, bob_px, bob_dx, rt.stream())
+            def guarded(name, leg):
+                """An informational leg must never cost the line its headline: a failure is recorded under the leg's name."""
+                try:
+                    out[name] = leg()
+                except Exception as exc:  # pragma: no cover
+                    out[name] = {"error": repr(exc)[:300]}
 
-            out["interactive_protocol"] = interactive_protocol_leg(torch, eng, parties, ns, shard_inputs, x_enc, y_enc, expect, l, B, value, one_more_party)
-            # ---- BASELINE configs[0]: the latency of ONE comparison through the product (no CPU path)
-            out["latency_single"] = latency_single_leg(torch, eng, keys)
-            out["latency_single"]["cpu_oracle_ms"] = out.get("cpu_baseline", {}).get("configs0_single_core_ms")
-            # ---- online phase only (reported, never `value`): randomizers pre-generated into device pools (untimed), as the
-            # reference pre-generates them in background workers (boot_randomness_generation, SC/initiator.py:205-210)
-            gen = torch.Generator(device=eng.device)
-            gen.manual_seed(1234)
-            boot_pools(B, l, alice_p, alice_d, bob_p, bob_d, source="torch", generator=gen)
-            rt.synchronize()
-            to = time.perf_counter()
-            ro = secure_comparison_batch(x_enc, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws, randomize="pool")
-            rt.synchronize()
-            online_s = time.perf_counter() - to
-            dec_o = bob_p.decrypt_raw_batch(ro)
-            out["online_phase_only"] = {"value": B / online_s, "unit": "comparisons/s", "correct": bool((dec_o[:, 0] == expect).all().item()),
-                                        "note": "all 4 + 2(l+1) randomizer exponentiations per comparison pre-generated (excluded); informational"}
-            # ---- PCIe-inclusive rate (reported at N = 1, never `value`): inputs start in pinned host memory, result returns to the host
-            names = ("r", "delta_a", "rhos", "rho_z", "r_bob_dgk", "r_alice_dgk", "rho_zeta_1", "rho_zeta_2", "rho_delta_b")
-            host_in = [t.cpu().pin_memory() for t in (x_enc, y_enc) + tuple(getattr(draws, n_) for n_ in names)]
-            host_perm = None if draws.permutation is None else draws.permutation.cpu().pin_memory()
-            for _ in range(2):                                # the first pass pays for the allocator's first-time hipMallocs
+            def leg_window_sensitivity():
+                # ---- how much of `value` hangs on the 6 GB window-20 table: the same step with smaller fixed-base windows
+                sens = {str(args.fb_window): {"value": value, "table_bytes": table_bytes, "table_build_s": table_build_s}}
+                for w in (8, 16, 20):
+                    if w == args.fb_window:
+                        continue
+                    ps_w, bs_w, tb_w = build_parties(w)
+                    step_w, close_w = make_step(ps_w)
+                    step_w()
+                    dt_w, _ = timed(step_w, 2)
+                    close_w()
+                    sens[str(w)] = {"value": B * 2 / dt_w, "table_bytes": tb_w, "table_build_s": bs_w}
+                    del ps_w, step_w, close_w
+                    rt.empty_cache()
+                return sens
+
+            def leg_interactive_protocol():
+                # ---- the real two-party batch protocol (SURVEY 8(f1)/(f2); reported, never `value`): Initiator / KeyHolder
+                # .perform_secure_comparison_batch with draws=None over the in-memory transport -- every random input drawn on the
+                # device by the library's CSPRNG inside the timed region, messages handed over as device arrays (or, second figure,
+                # serialized through one pinned host buffer per message as a real transport would need)
+                def one_more_party():      # a further session's context and scheme objects (same keys, the first context's tables)
+                    e_x = rt.new_engine()
+                    e_x.set_latency_mode(args.latency_mode)
+                    e_x.set_onelane_mode(args.onelane_mode)
+                    bob_px = Paillier(p * q, p, q, engine=e_x, use_crt=use_crt)
+                    bob_dx = DGK(H("p") * H("q"), H("g"), H("h"), H("u"), dj["t"], H("p"), H("q"), H("v_p"), H("v_q"), engine=e_x,
+                                 randomizer_bits=args.rbits, fixed_base_window=args.fb_window, use_crt=use_crt)
+                    alice_dx = bob_dx.public_copy()
+                    bob_dx.share_tables_from(parties[0].bob_dgk)
+                    alice_dx.share_tables_from(parties[0].alice_dgk)
+                    alice_dx.prepare(), bob_dx.prepare()
+                    alice_px = bob_px.public_copy()
+                    _ = bob_px.key, alice_px.key
+                    return PartySet(alice_px, alice_dx, bob_px, bob_dx, rt.stream())
+
+                return interactive_protocol_leg(torch, eng, parties, ns, shard_inputs, x_enc, y_enc, expect, l, B, value, one_more_party)
+
+            def leg_latency_single():
+                # ---- BASELINE configs[0]: the latency of ONE comparison through the product (no CPU path)
+                ls_ = latency_single_leg(torch, eng, keys)
+                ls_["cpu_oracle_ms"] = out.get("cpu_baseline", {}).get("configs0_single_core_ms")
+                return ls_
+
+            def leg_online_phase_only():
+                # ---- online phase only (reported, never `value`): randomizers pre-generated into device pools (untimed), as the
+                # reference pre-generates them in background workers (boot_randomness_generation, SC/initiator.py:205-210)
+                gen = torch.Generator(device=eng.device)
+                gen.manual_seed(1234)
+                boot_pools(B, l, alice_p, alice_d, bob_p, bob_d, source="torch", generator=gen)
                 rt.synchronize()
-                tp = time.perf_counter()
-                dv = [t.to(eng.device, non_blocking=True) for t in host_in]
-                d2 = BatchDraws(permutation=None if host_perm is None else host_perm.to(eng.device, non_blocking=True),
-                                **{n_: dv[2 + i] for i, n_ in enumerate(names)})
-                r2 = secure_comparison_batch(dv[0], dv[1], l, alice_p, alice_d, bob_p, bob_d, d2, randomize=True).cpu()
+                to = time.perf_counter()
+                ro = secure_comparison_batch(x_enc, y_enc, l, alice_p, alice_d, bob_p, bob_d, draws, randomize="pool")
                 rt.synchronize()
-                pcie_s = time.perf_counter() - tp
-                del dv, d2
-            out["pcie_inclusive"] = {"value": B / pcie_s, "unit": "comparisons/s", "host_bytes_per_comparison":
-                                     sum(t.numel() * t.element_size() for t in host_in) / B + r2.shape[-1] * 4}
+                online_s = time.perf_counter() - to
+                dec_o = bob_p.decrypt_raw_batch(ro)
+                return {"value": B / online_s, "unit": "comparisons/s", "correct": bool((dec_o[:, 0] == expect).all().item()),
+                                            "note": "all 4 + 2(l+1) randomizer exponentiations per comparison pre-generated (excluded); informational"}
+
+            def leg_pcie_inclusive():
+                # ---- PCIe-inclusive rate (reported at N = 1, never `value`): inputs start in pinned host memory, result returns to the host
+                names = ("r", "delta_a", "rhos", "rho_z", "r_bob_dgk", "r_alice_dgk", "rho_zeta_1", "rho_zeta_2", "rho_delta_b")
+                host_in = [t.cpu().pin_memory() for t in (x_enc, y_enc) + tuple(getattr(draws, n_) for n_ in names)]
+                host_perm = None if draws.permutation is None else draws.permutation.cpu().pin_memory()
+                for _ in range(2):                                # the first pass pays for the allocator's first-time hipMallocs
+                    rt.synchronize()
+                    tp = time.perf_counter()
+                    dv = [t.to(eng.device, non_blocking=True) for t in host_in]
+                    d2 = BatchDraws(permutation=None if host_perm is None else host_perm.to(eng.device, non_blocking=True),
+                                    **{n_: dv[2 + i] for i, n_ in enumerate(names)})
+                    r2 = secure_comparison_batch(dv[0], dv[1], l, alice_p, alice_d, bob_p, bob_d, d2, randomize=True).cpu()
+                    rt.synchronize()
+                    pcie_s = time.perf_counter() - tp
+                    del dv, d2
+                return {"value": B / pcie_s, "unit": "comparisons/s", "host_bytes_per_comparison":
+                                         sum(t.numel() * t.element_size() for t in host_in) / B + r2.shape[-1] * 4}
+
+            guarded("window_sensitivity", leg_window_sensitivity)
+            guarded("interactive_protocol", leg_interactive_protocol)
+            guarded("latency_single", leg_latency_single)
+            guarded("online_phase_only", leg_online_phase_only)
+            guarded("pcie_inclusive", leg_pcie_inclusive)
         if not args.no_other_configs and world == 1 and (B, l, args.pbits) == (65536, 32, 2048):
             # ---- the other BASELINE shapes that fit one GPU, by the same code path, so that they are driver-run numbers too
             import copy
