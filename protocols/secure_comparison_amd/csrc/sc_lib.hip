@@ -1359,28 +1359,39 @@ int sc_dgk_step4(sc_ctx* ctx, int mod, int cst_g, int cst_ginv, int l, const uin
     return fail(ctx, SC_ERR_ARG, "sc_dgk_step4: bad constant");
   const Mod& m = ctx->mods[mod];
   std::string key = "step4:" + std::to_string(mod) + ":" + std::to_string(cst_g) + ":" + std::to_string(cst_ginv) + ":" + std::to_string(l);
-  // ---- launch (a): per comparison park  one, g^s*, d', d'^-1 ... in a limb-form side buffer `park` [NP][count][S]
-  //   entries: 0 = one, 1 = d' (Montgomery), 2 = d'^-1, 3 = gs0 = g^s, 4 = gs1 = g^s * g, 5 = g^delta_a
-  const int NP = 6;
+  // Per comparison and bit the step formulas (SC/initiator.py:317-320, 368-371, 471-482) multiply by factors that depend only on the
+  // comparison and on the two flag bits (alpha_i, alpha~_i):
+  //   w_i = base_i * K[alpha_i][alpha~_i],   base_i = [beta_i] (alpha_i = 0) or [beta_i]^-1 (alpha_i = 1),
+  //         K = 1, d'^-1, g d'^-1, g   for (0,0), (0,1), (1,0), (1,1)      (4d: [1] - [beta_i] = g [beta_i]^-1; 4e: - [d] where the bits differ)
+  //   c_i = [beta_i]^-1 * C[alpha_i][alpha~_i] * (w_sum)^3,
+  //         C = g^s, g^s d', g^s g d'^-1, g^s g                            (4h: [s] + alpha_i + [d] (alpha~_i - alpha_i))
+  // so launch (a) computes the six factors that are not constants once per comparison and parks them, and the bit loop of launch
+  // (b) spends 7 products per bit instead of 9 (round 3 multiplied g, d'^-1, D and g^s g^alpha in one after the other, by the
+  // residue 1 where a factor did not apply).  Same factors, another order: the canonical residues are the same.
+  //   park entries: 0 = K01 = d'^-1, 1 = K10 = g d'^-1, 2 = C00 = g^s, 3 = C01 = g^s d', 4 = C10 = g^s g d'^-1, 5 = C11 = g^s g, 6 = g^delta_a
+  const int NP = 7;
   uint32_t* d_park;
   { int rc0 = tmp_buf(ctx, TMP_PARK, (size_t)NP * count * m.S * 4, (void**)&d_park); if (rc0) return rc0; }
-  std::string ka = key + ":a", kb = key + ":b";
+  std::string ka = key + ":a2", kb = key + ":b2";
   auto ita = ctx->progs.find(ka);
   if (ita == ctx->progs.end()) {
     Builder bd; const int cg = bd.use_const(cst_g), cgi = bd.use_const(cst_ginv);
-    // scratch: 0 one, 1 g, 2 ginv, 3 d, 4 dinv
-    bd.loadt_const(1); bd.stt(0); bd.storel(4, 0);
+    // scratch: 0 one, 1 g, 2 ginv, 3 d, 4 dinv, 5 d', 6 d'^-1, 7 gs0 = g^s
+    bd.loadt_const(1); bd.stt(0);
     bd.loadt_const(cg); bd.stt(1);
     bd.loadt_const(cgi); bd.stt(2);
     bd.loadw(0); bd.mul_const(0); bd.stt(3);
     bd.loadw(1); bd.mul_const(0); bd.stt(4);
     // d' = rsmall ? one : d ; d'^-1 likewise   (SC/initiator.py:289-290: [d] <- [0] = g^0 = 1)
-    bd.loadt_tblsel(2, 0, 2, 0, 3, 3, 0, 0); bd.storel(4, 1);
-    bd.loadt_tblsel(2, 0, 2, 0, 4, 4, 0, 0); bd.storel(4, 2);
-    // gs0 = g^s, s = 1 - 2 delta_a  (delta_a = 1 -> g^-1, SC/initiator.py:459-461)
-    bd.loadt_tblsel(3, 0, 3, 0, 1, 1, 2, 2); bd.storel(4, 3);
-    bd.mul_tbl(1); bd.storel(4, 4);                      // gs1 = g^s * g^1   (alpha_i = 1, :476)
-    bd.loadt_tblsel(3, 0, 3, 0, 0, 0, 1, 1); bd.storel(4, 5);   // g^delta_a (:484)
+    bd.loadt_tblsel(2, 0, 2, 0, 3, 3, 0, 0); bd.stt(5);
+    bd.loadt_tblsel(2, 0, 2, 0, 4, 4, 0, 0); bd.stt(6); bd.storel(4, 0);          // K01 = d'^-1
+    bd.mul_tbl(1); bd.storel(4, 1);                                                // K10 = g d'^-1
+    // g^s, s = 1 - 2 delta_a  (delta_a = 1 -> g^-1, SC/initiator.py:459-461)
+    bd.loadt_tblsel(3, 0, 3, 0, 1, 1, 2, 2); bd.stt(7); bd.storel(4, 2);          // C00 = g^s
+    bd.mul_tbl(5); bd.storel(4, 3);                                                // C01 = g^s d'
+    bd.loadt_tbl(7); bd.mul_tbl(1); bd.storel(4, 5);                               // C11 = g^s g            (alpha_i = 1, :476)
+    bd.mul_tbl(6); bd.storel(4, 4);                                                // C10 = g^s g d'^-1
+    bd.loadt_tblsel(3, 0, 3, 0, 0, 0, 1, 1); bd.storel(4, 6);                      // g^delta_a (:484)
     bd.end();
     Prog p; int rc = finalize_prog(ctx, m, bd, &p); if (rc) return rc;
     ita = ctx->progs.emplace(ka, p).first;
@@ -1393,42 +1404,33 @@ int sc_dgk_step4(sc_ctx* ctx, int mod, int cst_g, int cst_ginv, int l, const uin
   // ---- launch (b): the bit loop i = l-1 .. 0 (SC/initiator.py:471-482) then c_-1 (:484)
   auto itb = ctx->progs.find(kb);
   if (itb == ctx->progs.end()) {
-    Builder bd;
+    Builder bd; const int cg = bd.use_const(cst_g);
     // ext: 0 beta, 1 beta_inv, 2 park, 3 alpha, 4 alpha_tilde, 5 out
-    // scratch: 0 one, 1 d', 2 d'inv, 3 gs0, 4 gs1, 5 beta_i, 6 beta_i^-1, 7 g*beta_inv (xor when alpha_i=1), 8 w_sum, 9 xor*dinv, 10 xor, 11 w_sum^3 / tmp, 12 g
-    for (int e = 0; e < 5; e++) { bd.loadt_extl(2, e); bd.stt(e); }
-    // g itself = gs1 * gs0^-1 is not needed: xor for alpha_i = 1 is [1] * [beta_i]^-1 = g * beta_inv; park g as entry 12 via gs: g = (delta_a ? gs1*g^2.. ) -> simpler: constant
-    bd.touch(12);
+    // scratch: 0 K00 = one, 1 K01, 2 K10, 3 K11 = g, 4 C00, 5 C01, 6 C10, 7 C11, 8 beta_i, 9 beta_i^-1, 10 w_sum, 11 w_i^(2^i), 12 w_sum^3
+    bd.loadt_const(1); bd.stt(0);
+    bd.loadt_extl(2, 0); bd.stt(1);
+    bd.loadt_extl(2, 1); bd.stt(2);
+    bd.loadt_const(cg); bd.stt(3);
+    for (int e = 0; e < 4; e++) { bd.loadt_extl(2, 2 + e); bd.stt(4 + e); }
     for (int i = l - 1; i >= 0; i--) {
-      bd.loadw(0, i); bd.mul_const(0); bd.stt(5);                         // beta_i (Montgomery)
-      bd.loadw(1, i); bd.mul_const(0); bd.stt(6);                         // beta_i^-1
-      bd.mul_tbl(12); bd.stt(7);                                          // g * beta_i^-1          (4d, alpha_i = 1, :320)
-      // xor_i = alpha_i ? entry 7 : entry 5
-      bd.loadt_tblsel(3, i, 3, i, 5, 5, 7, 7); bd.stt(10);
-      // w_i = (alpha_i != alpha_tilde_i) ? xor_i * d'^-1 : xor_i          (4e, :368-371)   flags: fa = alpha_i, fb = alpha_tilde_i
-      bd.mul_tblsel(3, i, 4, i, 0, 2, 2, 0);
+      bd.loadw(0, i); bd.mul_const(0); bd.stt(8);                         // beta_i (Montgomery)
+      bd.loadw(1, i); bd.mul_const(0); bd.stt(9);                         // beta_i^-1
+      bd.loadt_tblsel(3, i, 3, i, 8, 8, 9, 9);                            // base_i                 (4d, :317-320)
+      bd.mul_tblsel(3, i, 4, i, 0, 1, 2, 3);                              // w_i = base_i K         (4d + 4e, :368-371)   flags: fa = alpha_i, fb = alpha~_i
       for (int k = 0; k < i; k++) bd.sqr();                               // w_i^(2^i)              (4f, :406)
-      bd.stt(9);
-      // c_i = g^s * g^alpha_i * D[alpha_tilde_i - alpha_i] * beta_i^-1 * (w_sum)^3       (4h, :471-482)
-      //   D: (fa, fb) = (0,0) -> one ; (0,1) -> d' (alpha_tilde - alpha = +1) ; (1,0) -> d'^-1 ; (1,1) -> one
-      bd.loadt_tbl(6);
-      bd.mul_tblsel(3, i, 4, i, 0, 1, 2, 0);
-      bd.mul_tblsel(3, i, 3, i, 3, 3, 4, 4);                              // g^s or g^s g
-      if (i != l - 1) bd.mul_tbl(11);                                     // (w_sum)^3 ; first iteration: `3 * 0` is the int 0 -> [0] = 1
+      bd.stt(11);
+      bd.loadt_tbl(9);
+      bd.mul_tblsel(3, i, 4, i, 4, 5, 6, 7);                              // [beta_i]^-1 C          (4h, :471-478)
+      if (i != l - 1) bd.mul_tbl(12);                                     // (w_sum)^3 ; first iteration: `3 * 0` is the int 0 -> [0] = 1
       bd.redc(); bd.storew(5, i + 1);
       // w_sum *= w_i ; keep its cube for the next bit
-      if (i == l - 1) { bd.loadt_tbl(9); } else { bd.loadt_tbl(8); bd.mul_tbl(9); }
-      bd.stt(8);
-      if (i > 0) { bd.sqr(); bd.mul_tbl(8); bd.stt(11); }
+      if (i == l - 1) { bd.loadt_tbl(11); } else { bd.loadt_tbl(10); bd.mul_tbl(11); }
+      bd.stt(10);
+      if (i > 0) { bd.sqr(); bd.mul_tbl(10); bd.stt(12); }
     }
-    bd.loadt_extl(2, 5); bd.mul_tbl(8); bd.redc(); bd.storew(5, 0);       // c_-1 = g^delta_a * w_sum (:484)
+    bd.loadt_extl(2, 6); bd.mul_tbl(10); bd.redc(); bd.storew(5, 0);      // c_-1 = g^delta_a * w_sum (:484)
     bd.end();
-    // entry 12 (g) is written by a tiny prologue: prepend ops
-    Builder pre; const int cg = pre.use_const(cst_g);
-    pre.loadt_const(cg); pre.stt(12);
-    pre.ops.insert(pre.ops.end(), bd.ops.begin(), bd.ops.end());
-    pre.nscratch = std::max(pre.nscratch, bd.nscratch); pre.muls = bd.muls; pre.redcs = bd.redcs; pre.sqrs = bd.sqrs;
-    Prog p; int rc = finalize_prog(ctx, m, pre, &p); if (rc) return rc;
+    Prog p; int rc = finalize_prog(ctx, m, bd, &p); if (rc) return rc;
     itb = ctx->progs.emplace(kb, p).first;
   }
   int rc;
