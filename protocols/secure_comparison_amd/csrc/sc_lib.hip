@@ -424,7 +424,7 @@ struct Builder {
   void mul_extl(int ext, uint32_t off = 0) { emit(OP_MUL, AK_EXTL, 0, ext, off); muls++; }
   void loadw(int ext, uint32_t off = 0, uint32_t woff = 0, uint32_t nw = 0) { emit(OP_LOADW, 0, 0, ext, off, (woff << 16) | nw); }
   // ext_set where bit `bit` of the item's u64 flag (ext flag_ext) is set, else ext_clear (sc_vm.h)
-  void loadw_sel(int ext_set, int ext_clear, int flag_ext, int bit) { emit(OP_LOADW, 0, 1, ext_set | (ext_clear << 4) | (flag_ext << 8) | (bit << 12)); }
+  void loadw_sel(int ext_set, int ext_clear, int flag_ext, int bit, uint32_t off = 0) { emit(OP_LOADW, 0, 1, ext_set | (ext_clear << 4) | (flag_ext << 8) | (bit << 12), off); }
   void add_flag(int flag_ext, int bit, bool invert) { emit(OP_ADD1, 0, 1, flag_ext | (bit << 4) | ((invert ? 1 : 0) << 12)); }
   void addw(int ext, uint32_t off = 0, uint32_t woff = 0, uint32_t nw = 0) { emit(OP_ADDW, 0, 0, ext, off, (woff << 16) | nw); }
   void loadt_const(int lds_idx) { emit(OP_LOADT, AK_CONST, 0, lds_idx); }
@@ -1252,29 +1252,34 @@ static int modinv_rec(sc_ctx* ctx, int mod, const uint32_t* x, uint32_t* out, ui
   { int rc0 = tmp_buf(ctx, TMP_INV_BASE + 2 * depth, (size_t)K * C * m.S * 4, (void**)&d_P); if (rc0) return rc0; }
   { int rc0 = tmp_buf(ctx, TMP_INV_BASE + 2 * depth + 1, (size_t)C * m.nwords * 4 * 2, (void**)&d_tot); if (rc0) return rc0; }
   d_totinv = d_tot + (size_t)C * m.nwords;
-  std::string k1 = "inv1:" + std::to_string(mod) + ":" + std::to_string(K), k2 = "inv2:" + std::to_string(mod) + ":" + std::to_string(K);
+  // No operand is converted to Montgomery form and no result reduced out of it: the prefix products simply drift by one factor
+  // 1/R per product,  Q_i = x_0 .. x_i / R^i  (Q_0 = x_0), the chunk total Q_{K-1} goes up the tree as it is (a residue like any
+  // other), and its inverse u_{K-1} = (x_0 .. x_{K-1})^-1 R^(K-1) comes back carrying exactly the powers of R that the way down
+  // divides out again:   x_i^-1 = u_i Q_{i-1} / R   and   u_{i-1} = u_i x_i / R = (x_0 .. x_{i-1})^-1 R^(i-1),   u_0 = x_0^-1.
+  // Three products per element (round 3: six -- two conversions, a reduction pass and the same three).  Elements past the end
+  // of the batch read as 1 and take part like any other factor.
+  std::string k1 = "inv1d:" + std::to_string(mod) + ":" + std::to_string(K), k2 = "inv2d:" + std::to_string(mod) + ":" + std::to_string(K);
   auto it1 = ctx->progs.find(k1);
   if (it1 == ctx->progs.end()) {
     Builder bd;
     for (uint32_t i = 0; i < K; i++) {
-      bd.loadw(0, i); bd.mul_const(0);
-      if (i > 0) bd.mul_extl(1, i - 1);
+      if (i == 0) bd.loadw(0, 0); else bd.mul_extw(0, i);
       bd.storel(1, i);
     }
-    bd.redc(); bd.storew(2); bd.end();
+    bd.storew(2); bd.end();
     Prog p; int rc = finalize_prog(ctx, m, bd, &p); if (rc) return rc;
     it1 = ctx->progs.emplace(k1, p).first;
   }
   auto it2 = ctx->progs.find(k2);
   if (it2 == ctx->progs.end()) {
     Builder bd;
-    bd.loadw(3); bd.mul_const(0);                         // inv (Montgomery form) of the chunk product
+    bd.loadw(3);                                           // u_{K-1}: the inverse of the chunk total
     for (uint32_t i = K - 1; i >= 1; i--) {
       bd.stt(0);
-      bd.mul_extl(1, i - 1); bd.redc(); bd.storew(4, i);  // x_i^-1 = inv * prefix_{i-1}
-      bd.loadw(0, i); bd.mul_const(0); bd.mul_tbl(0);     // inv *= x_i
+      bd.mul_extl(1, i - 1); bd.storew(4, i);              // x_i^-1 = u_i Q_{i-1} / R
+      bd.loadt_tbl(0); bd.mul_extw(0, i);                  // u_{i-1} = u_i x_i / R
     }
-    bd.redc(); bd.storew(4, 0); bd.end();
+    bd.storew(4, 0); bd.end();
     Prog p; int rc = finalize_prog(ctx, m, bd, &p); if (rc) return rc;
     it2 = ctx->progs.emplace(k2, p).first;
   }
@@ -1366,17 +1371,24 @@ int sc_dgk_step4(sc_ctx* ctx, int mod, int cst_g, int cst_ginv, int l, const uin
   //   c_i = [beta_i]^-1 * C[alpha_i][alpha~_i] * (w_sum)^3,
   //         C = g^s, g^s d', g^s g d'^-1, g^s g                            (4h: [s] + alpha_i + [d] (alpha~_i - alpha_i))
   // so launch (a) computes the six factors that are not constants once per comparison and parks them, and the bit loop of launch
-  // (b) spends 7 products per bit instead of 9 (round 3 multiplied g, d'^-1, D and g^s g^alpha in one after the other, by the
-  // residue 1 where a factor did not apply).  Same factors, another order: the canonical residues are the same.
-  //   park entries: 0 = K01 = d'^-1, 1 = K10 = g d'^-1, 2 = C00 = g^s, 3 = C01 = g^s d', 4 = C10 = g^s g d'^-1, 5 = C11 = g^s g, 6 = g^delta_a
+  // (b) spends 6 + i products per bit (round 3: 9 + i and a reduction pass; it multiplied g, d'^-1, D and g^s g^alpha in one after
+  // the other, by the residue 1 where a factor did not apply, and converted [beta_i], [beta_i]^-1 to Montgomery form first).
+  // No conversion and no reduction pass inside the loop: [beta_i] and [beta_i]^-1 enter as the plain residues they are,
+  //   * the K factors are parked with a second factor R (K R^2): plain base_i times K R^2 / R = w_i in Montgomery form, which is
+  //     what the squarings need;
+  //   * the C factors in Montgomery form (C R): plain [beta_i]^-1 times C R / R is plain, times (w_sum)^3 R / R is plain -- the
+  //     stored value; likewise g^delta_a is parked plain for c_-1.
+  // Same factors, another order: the canonical residues are the same.
+  //   park entries: 0 = K01 = d'^-1, 1 = K10 = g d'^-1 (both times R^2), 2 = C00 = g^s, 3 = C01 = g^s d', 4 = C10 = g^s g d'^-1,
+  //                 5 = C11 = g^s g (times R), 6 = g^delta_a (plain)
   const int NP = 7;
   uint32_t* d_park;
   { int rc0 = tmp_buf(ctx, TMP_PARK, (size_t)NP * count * m.S * 4, (void**)&d_park); if (rc0) return rc0; }
-  std::string ka = key + ":a2", kb = key + ":b2";
+  std::string ka = key + ":a3", kb = key + ":b3";
   auto ita = ctx->progs.find(ka);
   if (ita == ctx->progs.end()) {
     Builder bd; const int cg = bd.use_const(cst_g), cgi = bd.use_const(cst_ginv);
-    // scratch: 0 one, 1 g, 2 ginv, 3 d, 4 dinv, 5 d', 6 d'^-1, 7 gs0 = g^s
+    // scratch (Montgomery form): 0 one, 1 g, 2 ginv, 3 d, 4 dinv, 5 d', 6 d'^-1, 7 g^s, 8 g d'^-1
     bd.loadt_const(1); bd.stt(0);
     bd.loadt_const(cg); bd.stt(1);
     bd.loadt_const(cgi); bd.stt(2);
@@ -1384,14 +1396,15 @@ int sc_dgk_step4(sc_ctx* ctx, int mod, int cst_g, int cst_ginv, int l, const uin
     bd.loadw(1); bd.mul_const(0); bd.stt(4);
     // d' = rsmall ? one : d ; d'^-1 likewise   (SC/initiator.py:289-290: [d] <- [0] = g^0 = 1)
     bd.loadt_tblsel(2, 0, 2, 0, 3, 3, 0, 0); bd.stt(5);
-    bd.loadt_tblsel(2, 0, 2, 0, 4, 4, 0, 0); bd.stt(6); bd.storel(4, 0);          // K01 = d'^-1
-    bd.mul_tbl(1); bd.storel(4, 1);                                                // K10 = g d'^-1
+    bd.loadt_tblsel(2, 0, 2, 0, 4, 4, 0, 0); bd.stt(6);
+    bd.mul_const(0); bd.storel(4, 0);                                              // K01 = d'^-1          (R^2)
+    bd.loadt_tbl(6); bd.mul_tbl(1); bd.stt(8); bd.mul_const(0); bd.storel(4, 1);   // K10 = g d'^-1        (R^2)
     // g^s, s = 1 - 2 delta_a  (delta_a = 1 -> g^-1, SC/initiator.py:459-461)
     bd.loadt_tblsel(3, 0, 3, 0, 1, 1, 2, 2); bd.stt(7); bd.storel(4, 2);          // C00 = g^s
     bd.mul_tbl(5); bd.storel(4, 3);                                                // C01 = g^s d'
     bd.loadt_tbl(7); bd.mul_tbl(1); bd.storel(4, 5);                               // C11 = g^s g            (alpha_i = 1, :476)
-    bd.mul_tbl(6); bd.storel(4, 4);                                                // C10 = g^s g d'^-1
-    bd.loadt_tblsel(3, 0, 3, 0, 0, 0, 1, 1); bd.storel(4, 6);                      // g^delta_a (:484)
+    bd.loadt_tbl(7); bd.mul_tbl(8); bd.storel(4, 4);                               // C10 = g^s g d'^-1
+    bd.loadt_tblsel(3, 0, 3, 0, 0, 0, 1, 1); bd.redc(); bd.storel(4, 6);           // g^delta_a (:484), plain
     bd.end();
     Prog p; int rc = finalize_prog(ctx, m, bd, &p); if (rc) return rc;
     ita = ctx->progs.emplace(ka, p).first;
@@ -1406,29 +1419,25 @@ int sc_dgk_step4(sc_ctx* ctx, int mod, int cst_g, int cst_ginv, int l, const uin
   if (itb == ctx->progs.end()) {
     Builder bd; const int cg = bd.use_const(cst_g);
     // ext: 0 beta, 1 beta_inv, 2 park, 3 alpha, 4 alpha_tilde, 5 out
-    // scratch: 0 K00 = one, 1 K01, 2 K10, 3 K11 = g, 4 C00, 5 C01, 6 C10, 7 C11, 8 beta_i, 9 beta_i^-1, 10 w_sum, 11 w_i^(2^i), 12 w_sum^3
-    bd.loadt_const(1); bd.stt(0);
+    // scratch: 0 K00 = R^2, 1 K01, 2 K10, 3 K11 = g R^2, 4 C00, 5 C01, 6 C10, 7 C11, 8 w_sum, 9 w_sum^3
+    bd.loadt_const(0); bd.stt(0);
     bd.loadt_extl(2, 0); bd.stt(1);
     bd.loadt_extl(2, 1); bd.stt(2);
-    bd.loadt_const(cg); bd.stt(3);
+    bd.loadt_const(cg); bd.mul_const(0); bd.stt(3);
     for (int e = 0; e < 4; e++) { bd.loadt_extl(2, 2 + e); bd.stt(4 + e); }
     for (int i = l - 1; i >= 0; i--) {
-      bd.loadw(0, i); bd.mul_const(0); bd.stt(8);                         // beta_i (Montgomery)
-      bd.loadw(1, i); bd.mul_const(0); bd.stt(9);                         // beta_i^-1
-      bd.loadt_tblsel(3, i, 3, i, 8, 8, 9, 9);                            // base_i                 (4d, :317-320)
-      bd.mul_tblsel(3, i, 4, i, 0, 1, 2, 3);                              // w_i = base_i K         (4d + 4e, :368-371)   flags: fa = alpha_i, fb = alpha~_i
+      bd.loadw(1, i);                                                     // [beta_i]^-1, plain
+      bd.mul_tblsel(3, i, 4, i, 4, 5, 6, 7);                              // times C                (4h, :471-478)   flags: fa = alpha_i, fb = alpha~_i
+      if (i != l - 1) bd.mul_tbl(9);                                      // times (w_sum)^3 ; first iteration: `3 * 0` is the int 0 -> [0] = 1
+      bd.storew(5, i + 1);                                                // c_i
+      bd.loadw_sel(1, 0, 3, i, i);                                        // base_i, plain          (4d, :317-320)
+      bd.mul_tblsel(3, i, 4, i, 0, 1, 2, 3);                              // w_i = base_i K         (4d + 4e, :368-371), Montgomery form
       for (int k = 0; k < i; k++) bd.sqr();                               // w_i^(2^i)              (4f, :406)
-      bd.stt(11);
-      bd.loadt_tbl(9);
-      bd.mul_tblsel(3, i, 4, i, 4, 5, 6, 7);                              // [beta_i]^-1 C          (4h, :471-478)
-      if (i != l - 1) bd.mul_tbl(12);                                     // (w_sum)^3 ; first iteration: `3 * 0` is the int 0 -> [0] = 1
-      bd.redc(); bd.storew(5, i + 1);
-      // w_sum *= w_i ; keep its cube for the next bit
-      if (i == l - 1) { bd.loadt_tbl(11); } else { bd.loadt_tbl(10); bd.mul_tbl(11); }
-      bd.stt(10);
-      if (i > 0) { bd.sqr(); bd.mul_tbl(10); bd.stt(12); }
+      if (i != l - 1) bd.mul_tbl(8);                                      // w_sum *= w_i^(2^i)
+      bd.stt(8);
+      if (i > 0) { bd.sqr(); bd.mul_tbl(8); bd.stt(9); }                  // its cube for the next bit
     }
-    bd.loadt_extl(2, 6); bd.mul_tbl(10); bd.redc(); bd.storew(5, 0);      // c_-1 = g^delta_a * w_sum (:484)
+    bd.loadt_extl(2, 6); bd.mul_tbl(8); bd.storew(5, 0);                  // c_-1 = g^delta_a * w_sum (:484)
     bd.end();
     Prog p; int rc = finalize_prog(ctx, m, bd, &p); if (rc) return rc;
     itb = ctx->progs.emplace(kb, p).first;

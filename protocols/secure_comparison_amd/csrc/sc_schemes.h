@@ -76,7 +76,7 @@ struct PaillierKey {
   int r_k = -1, r_negk = -1, r_mq = -1;   // recombination modulo p^2, q^2 -> N^2 (randomizers)
   int d_k = -1, d_negk = -1, d_mq = -1;   // recombination modulo p, q -> N (decryption)
 };
-struct DgkHalf { int m = -1, m_v = -1, fbt = -1; };
+struct DgkHalf { int m = -1, m_v = -1, fbt = -1, c_g = -1; };   // c_g: g mod p (mod q)
 struct DgkKey {
   Big n, g, h, u; int nw = 0, rbits = 0, window = 0, t = 0;
   int mod_n = -1, cst_g = -1, cst_ginv = -1, fbt_h = -1;
@@ -349,6 +349,7 @@ int sc_dgk_key_create(sc_ctx* ctx, const uint32_t* n_hptr, const uint32_t* g_hpt
         rc = sc_mod_create(ctx, v.data(), (int)v.size(), &h.m_v); if (rc) return rc;
         // h has order v_p modulo p: h^r mod p = (h mod p)^(r mod v_p) -- a t-bit exponent and a half-size modulus
         rc = table(h.m, big_mod(k.h, pr), big_bits(v), std::min(window, 16), src ? (side ? src->hq.fbt : src->hp.fbt) : -1, &h.fbt); if (rc) return rc;
+        rc = reg_const(ctx, h.m, big_mod(k.g, pr), &h.c_g); if (rc) return rc;
       }
       const Big kk = big_modinv_odd(q, p);
       if (kk.empty()) return fail(ctx, SC_ERR_ARG, "sc_dgk_key_create: p and q are not coprime");
@@ -385,9 +386,10 @@ static int dgk_randomize_impl(sc_ctx* ctx, const DgkKey& k, const uint32_t* c, c
     rc = sc_fixedbase_pow(ctx, k.fbt_h, r, ewords, c, out, count); if (rc) return rc;
   } else if (!c) {
     // Key holder, CRT (SC/keyholder.py:106-108): h^r mod q, then h^r mod p with the first half of the recombination in the same
-    // launch -- t = (a_p - a_q) q^-1 mod p leaves the fixed-base program instead of a_p --, then a_q + q t with the g^bit factor of
-    // the unrandomized encryption in the same launch: five launches over the l + 1 values of every comparison instead of seven
-    // (each pass over the batch costs a load, a canonical store and the launch's ramp, whatever it multiplies).  Same residues.
+    // launch -- t = (a_p - a_q) q^-1 mod p leaves the fixed-base program instead of a_p --, then a_q + q t: five launches over the
+    // l + 1 values of every comparison instead of seven (each pass over the batch costs a load, a canonical store and the launch's
+    // ramp, whatever it multiplies).  The factor g^bit of the unrandomized encryption enters the two halves -- times g mod q, g mod p
+    // where the bit is set, two half-size products -- instead of the recombined value (one full-size product).  Same residues.
     uint32_t *r_red, *tq, *a_q;
     const int pw = ctx->mods[k.hp.m].nwords, qw = ctx->mods[k.hq.m].nwords;
     const int vpw = ctx->mods[k.hp.m_v].nwords, vqw = ctx->mods[k.hq.m_v].nwords;
@@ -395,12 +397,30 @@ static int dgk_randomize_impl(sc_ctx* ctx, const DgkKey& k, const uint32_t* c, c
     rc = tmp_words(ctx, TMP_S_B, count * pw, &tq); if (rc) return rc;
     rc = tmp_words(ctx, TMP_S_C, count * qw, &a_q); if (rc) return rc;
     rc = sc_modexp_shared(ctx, k.hq.m_v, k.exp_one, r, ewords, nullptr, r_red, count); if (rc) return rc;                 // r mod v_q
-    rc = sc_fixedbase_pow(ctx, k.hq.fbt, r_red, vqw, nullptr, a_q, count); if (rc) return rc;                               // a_q = h^r mod q
+    if (!bits) {
+      rc = sc_fixedbase_pow(ctx, k.hq.fbt, r_red, vqw, nullptr, a_q, count); if (rc) return rc;                             // a_q = h^r mod q
+    } else {
+      const Fbt f = ctx->fbts[k.hq.fbt];
+      const Mod mq = ctx->mods[k.hq.m];
+      std::string key = "fbcrt0:" + std::to_string(k.hq.fbt) + ":" + std::to_string(k.hq.c_g);
+      auto it = ctx->progs.find(key);
+      if (it == ctx->progs.end()) {
+        Builder bd; const int cg = bd.use_const(k.hq.c_g);
+        bd.loadt_fbt(0, 0, f.window, 0);
+        for (int j = 1; j < f.nwin; j++) bd.mul_fbt(0, j * f.window, f.window, j);
+        bd.emit(OP_MUL, AK_CONSTSEL, 0, 2, (uint32_t)1 | ((uint32_t)cg << 8)); bd.muls++;   // times g mod q where the bit is set
+        bd.redc(); bd.storew(1); bd.end();                                                   // a_q = g^bit h^r mod q
+        Prog pr; rc = finalize_prog(ctx, mq, bd, &pr); if (rc) return rc;
+        it = ctx->progs.emplace(key, pr).first;
+      }
+      VmExt ex[3] = {mk_ext(r_red, vqw, vqw), mk_ext(a_q, qw, qw), mk_ext(bits, 0, 0)};
+      rc = run_vm(ctx, k.hq.m, it->second, ex, 3, count, f.d_rows); if (rc) return rc;
+    }
     rc = sc_modexp_shared(ctx, k.hp.m_v, k.exp_one, r, ewords, nullptr, r_red, count); if (rc) return rc;                 // r mod v_p
     {
       const Fbt f = ctx->fbts[k.hp.fbt];
       const Mod mp = ctx->mods[k.hp.m];
-      std::string key = "fbcrt1:" + std::to_string(k.hp.fbt) + ":" + std::to_string(k.c_k) + ":" + std::to_string(k.c_negk) + ":" + std::to_string(qw);
+      std::string key = "fbcrt1:" + std::to_string(k.hp.fbt) + ":" + std::to_string(k.c_k) + ":" + std::to_string(k.c_negk) + ":" + std::to_string(qw) + (bits ? ":g" + std::to_string(k.hp.c_g) : "");
       auto it = ctx->progs.find(key);
       if (it == ctx->progs.end()) {
         Builder bd; const int ck = bd.use_const(k.c_k), cn = bd.use_const(k.c_negk);
@@ -408,7 +428,8 @@ static int dgk_randomize_impl(sc_ctx* ctx, const DgkKey& k, const uint32_t* c, c
         if (qw > mp.nwords) { int cid; rc = get_const_kred(ctx, k.hp.m, &cid); if (rc) return rc; kc = bd.use_const(cid); }
         bd.loadt_fbt(0, 0, f.window, 0);
         for (int j = 1; j < f.nwin; j++) bd.mul_fbt(0, j * f.window, f.window, j);
-        bd.redc();                                                                         // a_p = h^r mod p
+        if (bits) { const int cg = bd.use_const(k.hp.c_g); bd.emit(OP_MUL, AK_CONSTSEL, 0, 3, (uint32_t)1 | ((uint32_t)cg << 8)); bd.muls++; }   // times g mod p where the bit is set
+        bd.redc();                                                                         // a_p = [g^bit] h^r mod p
         bd.mul_const(ck); bd.stt(0);                                                       // a_p k,  k = q^-1 mod p
         if (qw > mp.nwords) emit_load_reduced(ctx, mp, bd, 1, qw, kc); else bd.loadw(1, 0, 0, qw);
         bd.mul_const(cn); bd.addt(0);                                                      // + a_q (p - k)
@@ -416,24 +437,23 @@ static int dgk_randomize_impl(sc_ctx* ctx, const DgkKey& k, const uint32_t* c, c
         Prog pr; rc = finalize_prog(ctx, mp, bd, &pr); if (rc) return rc;
         it = ctx->progs.emplace(key, pr).first;
       }
-      VmExt ex[3] = {mk_ext(r_red, vpw, vpw), mk_ext(a_q, qw, qw), mk_ext(tq, mp.nwords, mp.nwords)};
-      rc = run_vm(ctx, k.hp.m, it->second, ex, 3, count, f.d_rows); if (rc) return rc;
+      VmExt ex[4] = {mk_ext(r_red, vpw, vpw), mk_ext(a_q, qw, qw), mk_ext(tq, mp.nwords, mp.nwords), mk_ext(bits, 0, 0)};
+      rc = run_vm(ctx, k.hp.m, it->second, ex, bits ? 4 : 3, count, f.d_rows); if (rc) return rc;
     }
     {
       const Mod mn = ctx->mods[k.mod_n];
-      std::string key = "fbcrt2:" + std::to_string(k.mod_n) + ":" + std::to_string(k.c_mq) + ":" + std::to_string(pw) + ":" + std::to_string(qw) + (bits ? ":g" + std::to_string(k.cst_g) : "");
+      std::string key = "fbcrt2:" + std::to_string(k.mod_n) + ":" + std::to_string(k.c_mq) + ":" + std::to_string(pw) + ":" + std::to_string(qw);
       auto it = ctx->progs.find(key);
       if (it == ctx->progs.end()) {
         Builder bd; const int cm = bd.use_const(k.c_mq);
         bd.loadw(0, 0, 0, pw); bd.mul_const(cm);                                           // q t  (< p q: exact)
-        bd.addw(1, 0, 0, qw);                                                              // + a_q = h^r mod n
-        if (bits) { const int cg = bd.use_const(k.cst_g); bd.emit(OP_MUL, AK_CONSTSEL, 0, 3, (uint32_t)1 | ((uint32_t)cg << 8)); bd.muls++; }   // times g where the bit is set
+        bd.addw(1, 0, 0, qw);                                                              // + a_q = [g^bit] h^r mod n
         bd.storew(2); bd.end();
         Prog pr; rc = finalize_prog(ctx, mn, bd, &pr); if (rc) return rc;
         it = ctx->progs.emplace(key, pr).first;
       }
-      VmExt ex[4] = {mk_ext(tq, pw, pw), mk_ext(a_q, qw, qw), mk_ext(out, mn.nwords, mn.nwords), mk_ext(bits, 0, 0)};
-      return run_vm(ctx, k.mod_n, it->second, ex, 4, count);
+      VmExt ex[3] = {mk_ext(tq, pw, pw), mk_ext(a_q, qw, qw), mk_ext(out, mn.nwords, mn.nwords)};
+      return run_vm(ctx, k.mod_n, it->second, ex, 3, count);
     }
   } else {
     uint32_t *r_red, *part_p, *part_q;

@@ -70,6 +70,11 @@ def child() -> None:
     rate("zero tests + delta_B (k_vm<1,37>, 33B)", lambda: bob_d.any_zero_batch(c33p))
     rate("blind + rerandomize, 4i (k_vm<4,18>, 33B)", lambda: Initiator.step_4i_batch(c33p, alice_d, draws.rhos, None, draws.r_alice_dgk))
     rate("bob g^b h^r, CRT (k_vm<2,18>, 33B)", lambda: bob_d.randomize_batch(None, draws.r_bob_dgk.reshape((l + 1) * B, -1)))
+    bits33 = (torch.arange((l + 1) * B, device=c33.device) % 3 == 0).to(torch.uint8)
+    rate("bob encrypt bits g^b h^r, CRT (33B)", lambda: bob_d.encrypt_bits_randomized_batch(bits33, draws.r_bob_dgk.reshape((l + 1) * B, -1)))
+    flags = [(torch.arange(B, device=c33.device, dtype=torch.int64) * k) & ((1 << l) - 1) for k in (0x9E3779B1, 0x85EBCA77)]
+    one_bit = [(torch.arange(B, device=c33.device, dtype=torch.int64) >> k) & 1 for k in (1, 2)]
+    rate("steps 4c-4h with their inversions (k_vm<4,18>, B)", lambda: eng.initiator_step4(alice_d.key, l, c33p[0], c33p[1:], flags[0], flags[1], one_bit[0], one_bit[1]))
     rate("inversions mod n (33B)", lambda: alice_d.neg_batch(c33))
     rate("inversion mod N^2 (B)", lambda: alice_p.neg_batch(x_enc))
     print(json.dumps(out))
