@@ -348,7 +348,7 @@ int sc_dgk_key_create(sc_ctx* ctx, const uint32_t* n_hptr, const uint32_t* g_hpt
         if (!(v[0] & 1)) return fail(ctx, SC_ERR_ARG, "sc_dgk_key_create: v_p, v_q must be odd (they are primes)");
         rc = sc_mod_create(ctx, v.data(), (int)v.size(), &h.m_v); if (rc) return rc;
         // h has order v_p modulo p: h^r mod p = (h mod p)^(r mod v_p) -- a t-bit exponent and a half-size modulus
-        rc = table(h.m, big_mod(k.h, pr), big_bits(v), std::min(window, 16), src ? (side ? src->hq.fbt : src->hp.fbt) : -1, &h.fbt); if (rc) return rc;
+        rc = table(h.m, big_mod(k.h, pr), big_bits(v), std::min(window, 20), src ? (side ? src->hq.fbt : src->hp.fbt) : -1, &h.fbt); if (rc) return rc;
         rc = reg_const(ctx, h.m, big_mod(k.g, pr), &h.c_g); if (rc) return rc;
       }
       const Big kk = big_modinv_odd(q, p);

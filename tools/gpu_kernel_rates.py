@@ -34,7 +34,7 @@ def child() -> None:
         eng.set_onelane_mode(int(os.environ["KR_ONELANE"]))
     bob_p = Paillier(p * q, p, q)
     alice_p = bob_p.public_copy()
-    bob_d = DGK(H("p") * H("q"), H("g"), H("h"), H("u"), dj["t"], H("p"), H("q"), H("v_p"), H("v_q"), randomizer_bits=rbits, fixed_base_window=16)
+    bob_d = DGK(H("p") * H("q"), H("g"), H("h"), H("u"), dj["t"], H("p"), H("q"), H("v_p"), H("v_q"), randomizer_bits=rbits, fixed_base_window=int(os.environ.get("KR_WINDOW", bench.DEFAULT_FB_WINDOW)))
     alice_d = bob_d.public_copy()
     x, y, x_enc, y_enc, draws = bench.synth_inputs(eng, l, alice_p, bob_p, bob_d, B, rbits, 0)
     from protocols.secure_comparison_amd import Initiator
