@@ -400,7 +400,7 @@ def parse_args(argv=None):
                     "0 = automatic: 2 once every shard's widest launches still fill the chip (128 comparisons of 2048-bit keys per CU and shard, scaled by the square of the key size)")
     ap.add_argument("--side-stream", type=int, default=-1, help="run the randomizer exponentiations of a step on a second library context and stream per shard, "
                     "concurrently with the protocol's critical path (batch._AheadOfTime): 1 on, 0 off, -1 automatic (on while the batch leaves most wave slots empty: up to 32 comparisons per CU; measured +15 % at 4096, -2 % at 16384 on 256 CUs)")
-    ap.add_argument("--side-fork", type=int, default=0, help="fork mode (sc_ctx_set_fork_mode) of the second contexts")
+    ap.add_argument("--side-fork", type=int, default=1, help="fork mode (sc_ctx_set_fork_mode) of the second contexts: 1 = the q-side of the key holder's CRT on a second stream of that context, 0 = in sequence")
     ap.add_argument("--latency-mode", type=int, default=1, help="small-batch kernel policy (sc_ctx_set_latency_mode): 0 never, 1 automatic, 2 always")
     ap.add_argument("--onelane-mode", type=int, default=1, help="large-batch kernel policy for the 1024-bit primes (sc_ctx_set_onelane_mode): 0 never, 1 automatic, 2 always")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -534,7 +534,11 @@ def measure(args, torch, dist, rank: int, world: int, full: bool, rt=None):
         e_.set_latency_mode(args.latency_mode)
         e_.set_onelane_mode(args.onelane_mode)
     for e_ in side_engines:
-        e_.set_fork_mode(args.side_fork)      # the second context shares the GPU with the critical path: its CRT halves stay in sequence
+        # Bob's three Paillier randomizers are the second context's longest job and follow rho_z^N on its stream: with their p- and
+        # q-halves side by side (the same kernels: one copy of the code per CU) they are done before the critical path needs them,
+        # 113.7 k/s at configs[1] with every step within 1 % -- in sequence they were the step's longest chain whenever steps 2 .. 4i
+        # got faster (88 .. 103 k/s depending on which launch reached the chip first, profiles/r04_cfg1_second_context_fork.txt)
+        e_.set_fork_mode(args.side_fork)
 
     def build_parties(window: int) -> tuple[list[PartySet], float, int]:
         """Both parties' scheme objects per shard context.  The fixed-base tables are built once (first context) and shared

@@ -10,6 +10,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 BENCH="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-other-configs"
 echo "== kernel trace" && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $BENCH > $OUT/stats.log 2>&1 || { tail -5 $OUT/stats.log; exit 1; }
+echo "== kernel trace, single stream" && timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace1 -o trace1 -- python3 $BENCH --streams 1 > $OUT/trace1.log 2>&1 || { tail -5 $OUT/trace1.log; exit 1; }
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SALU GRBM_GUI_ACTIVE"; do
   name=pmcf_$(echo $set | tr ' ' '_' | cut -c1-60)
   echo "== pmc $set"
@@ -25,5 +26,5 @@ timeout -k 10 300 python3 bench.py --steps 4 --warmup 1 --batch 32768 --l 64 --p
 timeout -k 10 300 python3 tools/gpu_kernel_rates.py > $OUT/kernel_rates.txt 2>&1
 echo "== two-shard step dispatches"
 python3 tools/step_dispatches.py $(find $OUT/stats -name "*kernel_trace.csv" | head -1) 2 > $OUT/step_dispatches_two_shards.txt 2>&1
-python3 tools/step_glue.py $(find $OUT/pmcf_FETCH_SIZE -name "*kernel_trace.csv" | head -1) > $OUT/step_glue_single_stream.txt 2>&1
+python3 tools/step_glue.py $(find $OUT/trace1 -name "*kernel_trace.csv" | head -1) > $OUT/step_glue_single_stream.txt 2>&1
 echo done
