@@ -21,6 +21,8 @@ import sys
 import tempfile
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before the HIP runtime initialises: see protocols/secure_comparison_amd/__init__.py
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -792,6 +794,7 @@ def measure(args, torch, dist, rank: int, world: int, full: bool, rt=None):
                                               "of the kernel, never a timed launch) measured BEFORE the warm-up and AFTER the timed loop: a line whose value moved "
                                               "while these did not has changed code, one where they moved together has a chip in another clock state"},
             "policy": eng.policy(),
+            "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
             "modexp_per_s": {"P": B / launch_s, "D": d_rate,
                              "shapes": "P: %d-bit base ^ %d-bit exponent mod %d-bit (rho^N mod N^2); D: fixed base, %d-bit exponent mod %d-bit (h^r mod n)"
                                        % (args.pbits, args.pbits, 2 * args.pbits, args.rbits, dbits)},
