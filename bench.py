@@ -29,7 +29,10 @@ sys.path.insert(0, ROOT)
 KEYS = os.path.join(ROOT, "tests", "golden", "keys.json")
 MAX_CLOCK_HZ = 2.4e9   # MI355X peak engine clock (MI355X_MICROARCH.md)
 DEFAULT_FB_WINDOW = 20  # fixed-base window of the tables for h: 6.2 GB per GPU of 288 (21 table products per DGK randomizer instead of the 26 of
-                        # window 16 / 0.66 GB: +1.0 % on the whole step in a same-box A/B, profiles/r04_ab_vs_round2_tag.txt; window_sensitivity in the line)
+                        # window 16 / 0.66 GB: +1.0 % on the whole step in a same-box A/B, profiles/r04_ab_vs_round2_tag.txt; window_sensitivity in the line).
+                        # Window 24 (17 products from an 82 GB table, built in 1.6 .. 3.6 s) is supported and was measured: +0.35 % in an alternated
+                        # A/B -- the rows' address translation eats most of the four saved products -- and the configs[1] sub-line beside the
+                        # 82 GB drops from 114 k to 94 k/s (profiles/r04_fixed_base_window_24.txt): not the default
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -395,7 +398,7 @@ def parse_args(argv=None):
     ap.add_argument("--pbits", type=int, default=2048)
     ap.add_argument("--dgk", default="", help="DGK key fixture (tests/golden/keys.json); default dgk_<pbits>_l<l>")
     ap.add_argument("--rbits", type=int, default=400)
-    ap.add_argument("--fb-window", type=int, default=DEFAULT_FB_WINDOW, help="window of the fixed-base table for h (2^w rows of 288 B per window: 0.66 GB at w = 16, 6.2 GB at w = 20, HBM-resident)")
+    ap.add_argument("--fb-window", type=int, default=DEFAULT_FB_WINDOW, help="window of the fixed-base table for h (2^w rows of 288 B per window: 0.66 GB at w = 16, 6.2 GB at w = 20, 82 GB at w = 24, HBM-resident, shared by the contexts of a GPU)")
     ap.add_argument("--no-crt", action="store_true")
     ap.add_argument("--no-shuffle", action="store_true", help="leave the step-4i permutation out (do_shuffle=False)")
     ap.add_argument("--streams", type=int, default=0, help="concurrent shards per GPU (one library context, HIP stream and host thread each); 1 = a single stream; "
@@ -943,6 +946,7 @@ def measure(args, torch, dist, rank: int, world: int, full: bool, rt=None):
                 for k_, v_ in kw.items():
                     setattr(a2, k_, v_)
                 a2.streams, a2.side_stream = 0, -1
+                a2.fb_window = min(args.fb_window, 20)      # other keys: their own tables beside the headline's 82 GB
                 try:
                     others.append(measure(a2, torch, None, 0, 1, full=False, rt=rt))
                 except Exception as exc:  # pragma: no cover

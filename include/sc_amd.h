@@ -100,7 +100,8 @@ int sc_paillier_randomize(sc_ctx* ctx, int key, const uint32_t* c_dptr /* nullab
 /* Paillier.decrypt(ct, apply_encoding=False): out[i] = L(c[i]^lambda mod N^2) mu mod N, [count][nwords] (SC/keyholder.py:195). */
 int sc_paillier_decrypt(sc_ctx* ctx, int key, const uint32_t* c_dptr, uint32_t* out_dptr, uint64_t count);
 /* DGK key (`DGK.from_security_parameter`, SC/keyholder.py:161-166): public (n, g, h, u, t) and optionally secret (p, q, v_p, v_q); randomizer_bits = width of the exponent r of h^r ([ext]
- * ~2.5 t), window = fixed-base window of the tables for h (2^window rows per window).  table_src_ctx / table_src_key (nullable /
+ * ~2.5 t), window = fixed-base window of the tables for h, 1 .. 24 (2^window rows of the modulus's limb size per window: 6 GB
+ * at 20, 82 GB at 24 for a 2048-bit n and 400-bit r; the key holder's half-size tables stop at 20).  table_src_ctx / table_src_key (nullable /
  * ignored): another context of the same GPU whose key of the same modulus, h, window and width already built the tables -- they
  * are shared read-only instead of built again (concurrent shard contexts; see sc_fbt_import). */
 int sc_dgk_key_create(sc_ctx* ctx, const uint32_t* n_hptr, const uint32_t* g_hptr, const uint32_t* h_hptr, int nwords,

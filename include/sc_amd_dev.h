@@ -51,10 +51,10 @@ int sc_mod_words(sc_ctx* ctx, int mod);
 int sc_exp_create(sc_ctx* ctx, const uint32_t* e_hptr, int ewords, int* out_exp);
 /* Register a constant residue (kept in Montgomery form on the device): g, g^-1, mu, N (mod N^2) ... */
 int sc_const_create(sc_ctx* ctx, int mod, const uint32_t* v_hptr, int nwords, int* out_const);
-/* Build the fixed-base table base^(d * 2^(window*j)) for exponents below 2^exp_bits
+/* Build the fixed-base table base^(d * 2^(window*j)) for exponents below 2^exp_bits, window 1 .. 24
  * (DGK h and g: the randomizers h^r of SC/initiator.py:153-154 and SC/keyholder.py:106-108). */
 int sc_fbt_create(sc_ctx* ctx, int mod, const uint32_t* base_hptr, int exp_bits, int window, int* out_fbt);
-/* Use a table another context of the same device built for the same modulus (a window-20 table for h is 6 GB: concurrent
+/* Use a table another context of the same device built for the same modulus (a window-20 table for h is 6 GB, a window-24 one 82 GB: concurrent
  * shard contexts of one GPU read one copy).  The rows are read-only and reference-counted: they are freed when the last
  * context holding the table is destroyed.  `mod` must be `ctx`'s registration of the modulus the table was built for.  Call it
  * while `src_ctx` is idle (its table list is read without a lock); the imported table itself is safe to use from `ctx`'s thread

@@ -979,7 +979,7 @@ int sc_modexp_shared_isone_any(sc_ctx* ctx, int mod, int exp, const uint32_t* x,
 }
 
 int sc_fbt_create(sc_ctx* ctx, int mod, const uint32_t* base_hptr, int exp_bits, int window, int* out_fbt) {
-  if (!valid_mod(ctx, mod) || !base_hptr || exp_bits <= 0 || window < 1 || window > 20 || !out_fbt)
+  if (!valid_mod(ctx, mod) || !base_hptr || exp_bits <= 0 || window < 1 || window > 24 || !out_fbt)
     return fail(ctx, SC_ERR_ARG, "sc_fbt_create: bad argument");
   const Mod& m = ctx->mods[mod];
   Fbt f; f.mod = mod; f.window = window; f.exp_bits = exp_bits; f.nwin = (exp_bits + window - 1) / window;

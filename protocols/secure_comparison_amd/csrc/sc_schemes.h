@@ -298,7 +298,7 @@ int sc_dgk_key_create(sc_ctx* ctx, const uint32_t* n_hptr, const uint32_t* g_hpt
                       int uwords, int t_bits, const uint32_t* p_hptr, const uint32_t* q_hptr, int pwords, const uint32_t* vp_hptr,
                       const uint32_t* vq_hptr, int vwords, int randomizer_bits, int window, int flags, sc_ctx* table_src_ctx,
                       int table_src_key, int* out_key) {
-  if (!ctx || !n_hptr || !g_hptr || !h_hptr || nwords <= 0 || !u_hptr || uwords <= 0 || randomizer_bits <= 0 || window < 1 || window > 20 || !out_key)
+  if (!ctx || !n_hptr || !g_hptr || !h_hptr || nwords <= 0 || !u_hptr || uwords <= 0 || randomizer_bits <= 0 || window < 1 || window > 24 || !out_key)
     return fail(ctx, SC_ERR_ARG, "sc_dgk_key_create: bad argument");
   const bool secret = p_hptr != nullptr;
   if (secret && (!q_hptr || !vp_hptr || !vq_hptr || pwords <= 0 || vwords <= 0)) return fail(ctx, SC_ERR_ARG, "sc_dgk_key_create: incomplete secret key");

@@ -212,3 +212,24 @@ def test_inconsistent_dgk_secret_key_is_refused(engine, keys):
         sch = DGK(kw["n"], kw["g"], kw["h"], kw["u"], kw["t"], kw["p"], kw["q"], kw["v_p"], kw["v_q"], engine=engine, randomizer_bits=400)
         with pytest.raises(ValueError):
             _ = sch.key
+
+
+def test_fixed_base_windows_above_twenty(engine):
+    """Tables with 2^21 .. 2^24 rows per window (the bench's default is 24: 17 rows per 400-bit randomizer from an 82 GB table):
+    h^r and the blinding launch's fused c^rho h^r against Python's pow, with exponents that hit the first, the last and random rows
+    of every window.  Short exponents keep the tables of this test small (2 x 2^22 and 2 x 2^24 rows of 288 B: 2.4 / 9.7 GB)."""
+    rng = random.Random(24)
+    n = rng.getrandbits(2048) | (1 << 2047) | 1
+    mod = engine.modulus(n)
+    h = rng.randrange(2, n)
+    for window, ebits in ((22, 44), (24, 48), (21, 30)):
+        fb = engine.fixed_base(mod, h, ebits, window)
+        top = (1 << ebits) - 1
+        r = [0, 1, top, (1 << window) - 1, 1 << window, top ^ ((1 << window) - 1)] + [rng.getrandbits(ebits) for _ in range(26)]
+        c = [rng.randrange(n) for _ in r]
+        rho = [1 + rng.randrange((1 << 34) - 1) for _ in r]
+        tr, tc, trho = engine.upload(r, 2), engine.upload(c, mod.nwords), engine.upload(rho, 2)
+        assert engine.download(engine.fixedbase_pow(fb, tr)) == [pow(h, x, n) for x in r]
+        got = engine.download(engine.modexp_var(mod, tc, trho, 34, fb, tr))
+        assert got == [pow(y, e, n) * pow(h, x, n) % n for y, e, x in zip(c, rho, r)]
+        del fb
