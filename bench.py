@@ -376,7 +376,8 @@ def latency_single_leg(torch, eng, keys):
             "interactive_ms": fused_ms, "interactive_operator_path_ms": oper_ms, "static_step_chain_ms": statistics.median(t for t, _ in chain_runs),
             "correct": bool(ok_f and ok_o and dec == 1),
             "note": "interactive_ms: both players' perform_secure_comparison over the in-memory transport, steps as five library calls on one-element "
-                    "batches, every randomizer generated inside the call (median of 7 after a warm-up run); interactive_operator_path_ms: the same "
+                    "batches, every randomizer generated inside the call -- the key holder's three Paillier randomizers in the background on a second context, "
+                    "like the reference's background workers (KeyHolder.background_randomness; 11.9 ms without) -- (median of 7 after a warm-up run); interactive_operator_path_ms: the same "
                     "exchange with one launch per ciphertext operator (Initiator.fuse_steps = False), identical ciphertexts; static_step_chain_ms: "
                     "steps 1-7 without randomization as a batch of one.  A single comparison is a chain of dependent launches on an otherwise idle "
                     "chip: the product has no CPU path, cpu_oracle_ms (same box, one core) is the reference point"}

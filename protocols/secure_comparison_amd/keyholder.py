@@ -31,6 +31,8 @@ class BobPlain:
 class KeyHolder:
     """Player Bob."""
 
+    background_randomness = True     # single comparisons: Paillier randomizers generated beside the critical path (second context)
+
     fuse_steps = True      # see Initiator.fuse_steps
 
     def __init__(self, l_maximum_bit_length: int, communicator: Communicator | None = None, other_party: str = "",
@@ -188,7 +190,10 @@ class KeyHolder:
 
     def _start_randomness_generation(self) -> None:
         """3 Paillier + (l+1) DGK randomizers (SC/keyholder.py:174-179)."""
-        self.scheme_paillier.boot_randomness_generation(3)
+        # the three Paillier randomizers are not needed before step 5: generated beside the initiator's first message and
+        # Bob's own steps 2 .. 4b on a second context (the reference starts background workers here); the DGK ones are needed at
+        # once and cost a fixed-base launch
+        self.scheme_paillier.boot_randomness_generation(3, background=self.background_randomness)
         self.scheme_dgk.boot_randomness_generation(self.l_maximum_bit_length + 1)
 
     # ------------------------------------------------------------------ single-ciphertext steps

@@ -199,6 +199,8 @@ class _Scheme:
     def __init__(self, engine=None) -> None:
         self._engine = engine
         self._pool: list[int] = []
+        self._pending: list = []                     # background generation jobs (boot_randomness_generation(background=True))
+        self._background = None                      # (twin of this scheme on a second engine, its stream)
         self._batch_pool: torch.Tensor | None = None
 
     @property
@@ -232,18 +234,42 @@ class _Scheme:
         return self.engine.download(self.engine.modexp_var(m, self._one(a, m.nwords), e, 32 * ew))[0]
 
     # ---- randomness pool (boot_randomness_generation / get_randomness / shut_down of the templates package)
-    def boot_randomness_generation(self, amount: int) -> None:
-        """Pre-generate `amount` randomizers on the GPU (SC/initiator.py:209-210, SC/keyholder.py:178-179)."""
-        if amount > 0:
-            self._pool.extend(self._generate_randomness(amount))
+    def boot_randomness_generation(self, amount: int, background: bool = False) -> None:
+        """Pre-generate `amount` randomizers on the GPU (SC/initiator.py:209-210, SC/keyholder.py:178-179).
+        background: like the reference's generation in background workers -- the exponentiations are queued on a second library
+        context and stream of this scheme and the call returns; get_randomness collects them (waits, downloads) when the pool runs
+        dry.  For randomizers that are not needed at once: the key holder's three Paillier randomizers of step 5 are computed
+        while the initiator's first message is still being made.  Same pool, same order of use."""
+        if amount <= 0:
+            return
+        if background:
+            job = self._launch_randomness(amount)
+            if job is not None:
+                self._pending.append(job)
+                return
+        self._pool.extend(self._generate_randomness(amount))
+
+    def _launch_randomness(self, amount: int):
+        """(device array of `amount` finished randomizers, event) queued on the background context, or None where there is no
+        second context to be had (schemes without a background twin, the CPU test tier's stand-in engine)."""
+        return None
+
+    def _collect_pending(self) -> None:
+        t, ev, twin = self._pending.pop(0)
+        ev.synchronize()
+        self._pool.extend(twin.engine.download(t))
 
     def get_randomness(self) -> int:
+        if not self._pool and self._pending:
+            self._collect_pending()
         if not self._pool:
             warnings.warn(WARN_OUT_OF_RANDOMNESS, UserWarning)
             self._pool.extend(self._generate_randomness(1))
         return self._pool.pop()
 
     def shut_down(self) -> None:
+        while self._pending:
+            self._collect_pending()
         self._pool.clear()
         self._batch_pool = None
 
@@ -403,6 +429,27 @@ class Paillier(_Scheme):
 
         rho = uniform_below(self.public_key.n, amount, self.engine, source, generator, nonzero=True)
         return self.randomizer_batch(rho)
+
+    def _launch_randomness(self, amount: int):
+        from .engine import Engine
+
+        eng = self.engine
+        if not isinstance(eng, Engine):              # the CPU test tier's stand-in engine: nothing to overlap
+            return None
+        if self._background is None:
+            sk = self.secret_key
+            twin = Paillier(self.public_key.n, sk.p if sk else None, sk.q if sk else None, engine=Engine(eng.device_index),
+                            use_crt=self.use_crt, use_pairs=self.use_pairs, precision=self.precision)
+            self._background = (twin, torch.cuda.Stream(device=eng.device))
+        twin, stream = self._background
+        n = self.public_key.n
+        values = [1 + secrets.randbelow(n - 1) for _ in range(amount)]      # drawn now, in the caller's order
+        stream.wait_stream(torch.cuda.current_stream(eng.device))
+        with torch.cuda.stream(stream):
+            t = twin.randomizer_batch(twin.engine.upload(values, twin.mod_n.nwords))
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        return t, ev, twin
 
     def _apply_randomness(self, value: int, randomness: int) -> int:
         return self._mul_values(value, randomness)

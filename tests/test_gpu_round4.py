@@ -233,3 +233,36 @@ def test_fixed_base_windows_above_twenty(engine):
         got = engine.download(engine.modexp_var(mod, tc, trho, 34, fb, tr))
         assert got == [pow(y, e, n) * pow(h, x, n) % n for y, e, x in zip(c, rho, r)]
         del fb
+
+
+def test_background_randomizer_generation(engine, keys, monkeypatch):
+    """boot_randomness_generation(background=True): the key holder's Paillier randomizers queued on a second context and
+    collected when first needed -- the same values, in the same order of use, as the blocking form (rho^N mod N^2 of the draws)."""
+    import secrets as _secrets
+
+    from protocols.secure_comparison_amd import Paillier
+    from protocols.secure_comparison_amd import schemes as S
+
+    sk = oracle_paillier(keys, 1024)
+    drawn = []
+
+    def fake_randbelow(n):
+        v = (0x9E3779B97F4A7C15 * (len(drawn) + 1) ** 3 + 12345) % n
+        drawn.append(v)
+        return v
+
+    monkeypatch.setattr(S.secrets, "randbelow", fake_randbelow)
+    n2 = sk.n * sk.n
+    for background in (True, False):
+        drawn.clear()
+        sch = Paillier(sk.n, sk.p, sk.q, engine=engine)
+        sch.boot_randomness_generation(3, background=background)
+        assert len(drawn) == 3                                          # drawn at boot time in both forms
+        assert bool(sch._pending) == background
+        got = [sch.get_randomness() for _ in range(3)]
+        want = [pow(1 + v, sk.n, n2) for v in drawn[:3]]
+        assert got == want[::-1]                                        # the pool is used from its end (list.pop)
+        sch.boot_randomness_generation(2, background=background)
+        sch.shut_down()                                                 # collects what is still in flight
+        assert not sch._pending and not sch._pool
+    assert _secrets is S.secrets
