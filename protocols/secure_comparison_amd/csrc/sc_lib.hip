@@ -130,14 +130,14 @@ const Config kOneLane = {1, 37, 28, false};
 // of the CU -- 2.6x a squaring instead of 1.4x, a net loss of 12 % on x^p mod p^2; the one-lane form is used where it wins:
 // the single-modulus exponentiations)
 // (8,5) / (16,5): the SMALL-BATCH pair configurations of 1024 / 2048-bit moduli (kLatencyPair below)
-inline bool pair_capable(int G, int L, int W) { return W == 29 && (L == 18 || (L == 14 && (G == 4 || G == 8)) || (L == 5 && (G == 8 || G == 16))); }
+inline bool pair_capable(int G, int L, int W) { return W == 29 && (L == 18 || (L == 14 && (G == 4 || G == 8)) || (L == 5 && (G == 4 || G == 8 || G == 16))); }
 // Small batches of pair exponentiations (Alice's rho^N mod N^2, the key holder's c^(p-1) mod p^2 at B = 4096) are one dependent
 // chain of ~2400 pair squarings per item, and a wave's time per squaring is its own instruction count: S limb steps of
 // (L + L/2) multiply-adds + ~7 bookkeeping instructions each, whatever the number of lanes.  When even the (2G, 9) form
 // leaves half of the SIMDs without a wave, 4x the lanes with 5 limbs each -- (16,5) for 2048-bit, (8,5) for 1024-bit moduli,
 // S = 80 / 40 limbs -- shorten every limb step from ~22 to ~15 instructions at a multiply-add density (45 %) that would be
 // wasteful on a full chip but costs nothing on an empty one.  A twin context of the same modulus, like the other twins.
-const Config kLatencyPair16 = {16, 5, 29, false}, kLatencyPair8 = {8, 5, 29, false};
+const Config kLatencyPair16 = {16, 5, 29, false}, kLatencyPair8 = {8, 5, 29, false}, kLatencyPair4 = {4, 5, 29, false};   // (4,5): 512-bit primes of 1024-bit keys
 
 struct Mod {
   int G = 0, L = 0, W = 29, S = 0, nwords = 0, nbits = 0;
@@ -584,7 +584,8 @@ int run_pvm(sc_ctx* ctx, int mod, const Prog& p, const VmExt* exts, int next, ui
   for (int i = 0; i < next; i++) a.ext[i] = exts[i];
   ctx->mac_counter += (double)count * p.muls_per_item;   // pair programs carry their exact multiply-add count here
   if (!pair_capable(m.G, m.L, m.W)) return fail(ctx, SC_ERR_UNSUPPORTED, "no pair kernel for G=%d L=%d", m.G, m.L);
-  if (use_latency_config(ctx, m, count) && (m.G == 2 || m.G == 4)) {
+  if (use_latency_config(ctx, m, count) && (m.G == 1 || m.G == 2 || m.G == 4)) {
+    if (m.G == 1) return launch_pvm_cfg<2, 9>(ctx, a);      // the 512-bit primes of 1024-bit keys (BASELINE configs[0])
     if (m.G == 2) return launch_pvm_cfg<4, 9>(ctx, a);
     return launch_pvm_cfg<8, 9>(ctx, a);
   }
@@ -602,6 +603,7 @@ int run_pvm(sc_ctx* ctx, int mod, const Prog& p, const VmExt* exts, int next, ui
     case 8: return m.n0inv == 1 ? launch_pvm_cfg<8, 14, 29, true>(ctx, a) : launch_pvm_cfg<8, 14>(ctx, a);
   }
   if (m.L == 5) switch (m.G) {
+    case 4: return launch_pvm_cfg<4, 5>(ctx, a);
     case 8: return launch_pvm_cfg<8, 5>(ctx, a);
     case 16: return launch_pvm_cfg<16, 5>(ctx, a);
   }
@@ -1537,15 +1539,15 @@ static int pair_twin(sc_ctx* ctx, int mod) {
   return twin;
 }
 
-// The small-batch pair twin of `mod` ((16,5) for a (4,18) modulus, (8,5) for a (2,18) one) when this batch should run on it, else
+// The small-batch pair twin of `mod` ((16,5) for a (4,18) modulus, (8,5) for a (2,18) one, (4,5) for a (1,18) one) when this batch should run on it, else
 // -1.  Automatic policy: the (2G, 9) launch would still leave at least half of the SIMDs without a wave.
 static int latency_pair_twin(sc_ctx* ctx, int mod, uint64_t count) {
   if (ctx->latency_mode == 0) return -1;
   const Config* cfg = nullptr;
   {
     const Mod& m = ctx->mods[mod];
-    if (m.W != 29 || m.L != 18 || (m.G != 2 && m.G != 4)) return -1;
-    cfg = (m.G == 4) ? &kLatencyPair16 : &kLatencyPair8;
+    if (m.W != 29 || m.L != 18 || (m.G != 1 && m.G != 2 && m.G != 4)) return -1;
+    cfg = (m.G == 4) ? &kLatencyPair16 : (m.G == 2 ? &kLatencyPair8 : &kLatencyPair4);
     const uint64_t per_wave = 64 / (2 * m.G), waves = (count + per_wave - 1) / per_wave;
     if (ctx->latency_mode == 1 && waves > (uint64_t)ctx->num_cu * 2 / (uint64_t)ctx->chip_share) return -1;
     if (m.nbits + 8 > cfg->W * cfg->G * cfg->L || 32 * m.nwords > cfg->W * cfg->G * cfg->L) return -1;

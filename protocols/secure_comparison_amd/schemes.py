@@ -118,7 +118,7 @@ class _Ciphertext:
             warnings.warn(WARN_UNFRESH_SERIALIZATION, UserWarning)
             self.randomize()
         self._fresh = False
-        return type(self)(self._raw_value, self.scheme)
+        return type(self)(self._raw_value, self.scheme.for_wire())     # what arrives is bound to the PUBLIC scheme
 
     @property
     def fresh(self) -> bool:
@@ -201,6 +201,7 @@ class _Scheme:
         self._pool: list[int] = []
         self._pending: list = []                     # background generation jobs (boot_randomness_generation(background=True))
         self._background = None                      # (twin of this scheme on a second engine, its stream)
+        self._wire_copy = None                       # the public copy a transport hands to the other party (for_wire)
         self._batch_pool: torch.Tensor | None = None
 
     @property
@@ -208,6 +209,15 @@ class _Scheme:
         if self._engine is None:
             self._engine = default_engine()
         return self._engine
+
+    def for_wire(self):
+        """What a transport puts on the wire for a scheme: its PUBLIC part (the reference's serializers drop the secret key).  One
+        public copy per scheme object, so that everything a party receives from this scheme's owner is bound to the same object."""
+        if getattr(self, "secret_key", None) is None:
+            return self
+        if self._wire_copy is None:
+            self._wire_copy = self.public_copy()
+        return self._wire_copy
 
     # ---- single-value helpers: one-element batches on the GPU
     def _one(self, value: int, nwords: int) -> torch.Tensor:

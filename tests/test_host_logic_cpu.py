@@ -454,3 +454,25 @@ def test_pooled_batch_mode(world):
                                       L, alice_p, alice_d, bob_p, bob_d, draws, randomize="pool")
     assert [osk.dec_raw(v) for v in eng.download(res)] == [int(x <= y) for x, y in zip(xs, ys)]
     assert all(s._batch_pool.shape[0] == 0 for s in (alice_p, alice_d, bob_p, bob_d))
+
+
+def test_in_memory_transport_hands_over_public_schemes_only(world):
+    """What Alice receives over the in-memory transport is what a serializing transport would give her: the PUBLIC parts of Bob's
+    schemes (the reference's serializers drop the secret key) and ciphertexts bound to them -- never Bob's own scheme objects."""
+    from protocols.secure_comparison_amd.communicator import InMemoryCommunicator
+
+    _, _, _, bob_p, bob_d = world
+    comm = InMemoryCommunicator()
+
+    async def go():
+        bob_p.boot_randomness_generation(1)
+        ct = bob_p.unsafe_encrypt(5)
+        ct.randomize()
+        await comm.send("alice", (bob_p, bob_d, [ct]), msg_id="m")
+        return await comm.peer().recv("bob", msg_id="m")
+
+    got_p, got_d, (got_ct,) = asyncio.run(go())
+    assert got_p is not bob_p and got_p.secret_key is None and got_p == bob_p
+    assert got_d is not bob_d and got_d.secret_key is None and got_d == bob_d
+    assert got_ct.scheme is got_p and got_ct.peek_value() > 0
+    assert bob_p.for_wire() is got_p and got_p.for_wire() is got_p          # one public copy per scheme object
