@@ -21,7 +21,7 @@ import sys
 import tempfile
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before the HIP runtime initialises: see protocols/secure_comparison_amd/__init__.py
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")   # before the HIP runtime initialises: see protocols/secure_comparison_amd/__init__.py
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
