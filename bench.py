@@ -407,6 +407,7 @@ def parse_args(argv=None):
     ap.add_argument("--side-stream", type=int, default=-1, help="run the randomizer exponentiations of a step on a second library context and stream per shard, "
                     "concurrently with the protocol's critical path (batch._AheadOfTime): 1 on, 0 off, -1 automatic (on while the batch leaves most wave slots empty: up to 32 comparisons per CU; measured +15 % at 4096, -2 % at 16384 on 256 CUs)")
     ap.add_argument("--side-fork", type=int, default=1, help="fork mode (sc_ctx_set_fork_mode) of the second contexts: 1 = the q-side of the key holder's CRT on a second stream of that context, 0 = in sequence")
+    ap.add_argument("--fork-mode", type=int, default=1, help="fork mode of the shard contexts (sc_ctx_set_fork_mode): 0 never, 1 automatic (small batches), 2 always")
     ap.add_argument("--latency-mode", type=int, default=1, help="small-batch kernel policy (sc_ctx_set_latency_mode): 0 never, 1 automatic, 2 always")
     ap.add_argument("--onelane-mode", type=int, default=1, help="large-batch kernel policy for the 1024-bit primes (sc_ctx_set_onelane_mode): 0 never, 1 automatic, 2 always")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -536,6 +537,8 @@ def measure(args, torch, dist, rank: int, world: int, full: bool, rt=None):
     use_side = bool(args.side_stream) if args.side_stream >= 0 else (B <= 32 * cus)
     engines = [eng] + [rt.new_engine() for _ in range(1, ns)]
     side_engines = [rt.new_engine() for _ in range(ns)] if use_side else []
+    for e_ in engines:
+        e_.set_fork_mode(args.fork_mode)
     for e_ in engines + side_engines:
         e_.set_latency_mode(args.latency_mode)
         e_.set_onelane_mode(args.onelane_mode)

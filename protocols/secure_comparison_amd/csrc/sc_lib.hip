@@ -177,6 +177,7 @@ struct sc_ctx {
   std::vector<Const> consts;
   std::vector<Fbt> fbts;
   std::map<std::string, Prog> progs;
+  std::map<std::string, std::vector<Prog>> seg_progs;   // pair programs cut into segments (sc_modexp_shared_sq)
   uint32_t* scratch = nullptr;
   size_t scratch_bytes = 0;
   std::vector<void*> owned;
@@ -209,7 +210,7 @@ struct sc_ctx {
   // memory is a runtime blit kernel (__amd_rocclr_copyBuffer) that queues behind other contexts' chip-filling launches
   int* status_host[2] = {nullptr, nullptr};
   size_t status_cap[2] = {0, 0};
-  int fork_mode = 1;                                        // sc_ctx_set_fork_mode: 0 never fork inside a call, 1 automatic
+  int fork_mode = 1;                                        // sc_ctx_set_fork_mode: 0 never fork inside a call, 1 automatic (small batches), 2 always
   void* scheme_keys = nullptr;                              // Paillier / DGK key objects of the scheme-level entry points (sc_schemes.h)
   bool rng_seeded = false;
   std::atomic<uint64_t> rng_call{0};                        // generator calls since seeding: part of every keystream's nonce (atomic: two
@@ -320,10 +321,20 @@ struct AuxFork {
   }
   ~AuxFork() { (void)join(); }      // error paths: never leave the context on its second stream, nor forked work unordered
 };
-// Is a launch of `count` items of modulus `mod` small enough that a second, independent one fits beside it?  (A wave per SIMD
-// for both: half of the chip's 4 x CUs SIMDs each.)  Off with latency mode 0.
+// Should the two CRT halves of a call run side by side on two streams?  Small batches: when a second, independent launch fits
+// beside the first (a wave per SIMD for both: half of the chip's 4 x CUs SIMDs each; off with latency mode 0).  Large ones: when
+// this context has the chip to itself.
 inline bool small_enough_to_fork(const sc_ctx* ctx, const Mod& m, uint64_t count) {
-  if (ctx->latency_mode == 0 || ctx->fork_mode == 0 || ctx->in_aux) return false;
+  if (ctx->fork_mode == 0 || ctx->in_aux) return false;
+  if (ctx->fork_mode == 2) return true;                     // always: the two halves' launches beside each other whatever the batch size
+  // a context that has the chip to itself: the halves' launches side by side pack their partial rounds (three launches of 1.5
+  // rounds each are 2 rounds long one after the other) -- single-stream step 381.1 -> 377.2 ms at B = 65536; with concurrent
+  // shards the other shard's launches fill those rounds already and forking costs 1 % (profiles/r04_fork_modes.txt)
+  if (ctx->chip_share == 1 && ctx->latency_mode != 2) {
+    const uint64_t per_wave_full = std::max(1, 64 / m.G);
+    if ((count + per_wave_full - 1) / per_wave_full > (uint64_t)ctx->num_cu * 4) return true;
+  }
+  if (ctx->latency_mode == 0) return false;
   if (ctx->latency_mode == 2) return true;
   const uint64_t per_wave = std::max(1, 64 / (2 * m.G));     // in the small-batch configuration this batch would take
   return (count + per_wave - 1) / per_wave <= (uint64_t)ctx->num_cu * 4 / (uint64_t)ctx->chip_share;
@@ -1727,7 +1738,7 @@ int sc_ctx_set_chip_share(sc_ctx* ctx, int contexts) {
 }
 
 int sc_ctx_set_fork_mode(sc_ctx* ctx, int mode) {
-  if (!ctx || mode < 0 || mode > 1) return SC_ERR_ARG;
+  if (!ctx || mode < 0 || mode > 2) return SC_ERR_ARG;
   ctx->fork_mode = mode;
   return SC_OK;
 }
@@ -1827,7 +1838,59 @@ int sc_modexp_shared_sq(sc_ctx* ctx, int mod_m, int mod_m2, int exp, const uint3
   }
   {
     VmExt ex3[3] = {mk_ext(x, x_words, x_words), mk_ext(d_w, wm, wm), mk_ext(d_w1, wm, wm)};
-    int rc = run_pvm(ctx, mod_m, it1->second, ex3, 3, count); if (rc) return rc;
+    // A context that shares the chip (concurrent shards, sc_ctx_set_chip_share) runs a SINGLE-ROUND pair launch -- every resident
+    // wave holds its one group of items for the whole exponentiation: Alice's rho^N for a shard of 32768 is 2048 waves for 54 ms --
+    // in SEGMENTS: the same micro-program cut at window boundaries into a few launches, the pair parked in a row of the slot's
+    // table in between (slot = item while there is one round).  Waves of a launch retire together, so nothing another context
+    // queues behind such a launch gets a wave slot before it ends: the other shard's short, latency-bound launches (the inversion
+    // sweeps of steps 1 and 6 / 7, the assembly launch after ITS pair launch) were seen waiting 26 .. 32 ms each.  With segments
+    // they wait for a quarter of that.  Multi-round launches need none of this (their waves retire a round apart).
+    static const int want_segments = []{ const char* e = getenv("SC_PAIR_SEGMENTS"); return e ? atoi(e) : 4; }();
+    const uint64_t wave_items = (count + (uint64_t)(64 / m.G) - 1) / (uint64_t)(64 / m.G);
+    const bool segmented = want_segments > 1 && ctx->chip_share > 1 && !ctx->stamps && m.G == 4 && m.L == 18 && ex.bits >= 512 &&
+                           wave_items <= (uint64_t)ctx->num_cu * 4 * SC_PVM_WAVES && wave_items * 2 > (uint64_t)ctx->num_cu * 4 * SC_PVM_WAVES;
+    if (!segmented) {
+      int rc = run_pvm(ctx, mod_m, it1->second, ex3, 3, count); if (rc) return rc;
+    } else {
+      const int K = want_segments;
+      std::string ks = k1 + ":seg" + std::to_string(K);
+      auto its = ctx->seg_progs.find(ks);
+      if (its == ctx->seg_progs.end()) {
+        const Prog& full = it1->second;
+        std::vector<VmOp> ops(full.nops);
+        HIPCHK(ctx, hipMemcpy(ops.data(), full.d_ops, (size_t)full.nops * sizeof(VmOp), hipMemcpyDeviceToHost));
+        // cut after a PV_MULT (the end of a window) nearest to each k / K of the op list past the table build
+        std::vector<size_t> mults;
+        size_t body = 0;
+        for (size_t i = 0; i < ops.size(); i++) if ((ops[i].w0 & 0xff) == PV_MULT) mults.push_back(i);
+        for (size_t i = 0; i < ops.size(); i++) if ((ops[i].w0 & 0xff) == PV_SQR && i > 0 && (ops[i - 1].w0 & 0xff) == PV_LOADT) body = i;   // first squaring run after the first window's load
+        std::vector<size_t> cuts;      // index of the first op of segments 1 .. K-1
+        for (int k = 1; k < K; k++) {
+          const size_t target = body + (ops.size() - body) * (size_t)k / (size_t)K;
+          size_t best = 0;
+          for (size_t mi : mults) if (mi + 1 > body && (best == 0 || (mi + 1 > target ? mi + 1 - target : target - mi - 1) < (best > target ? best - target : target - best))) best = mi + 1;
+          if (best > (cuts.empty() ? body : cuts.back()) && best + 1 < ops.size()) cuts.push_back(best);
+        }
+        const uint32_t E = full.nscratch / 2;            // one more pair row of the slot's table: the parked state
+        std::vector<Prog> segs;
+        size_t from = 0;
+        for (size_t c = 0; c <= cuts.size(); c++) {
+          const size_t to = c < cuts.size() ? cuts[c] : ops.size();     // the last segment ends with the program's own PV_OUT, PV_END
+          std::vector<VmOp> so;
+          if (c > 0) so.push_back(VmOp{PV_LOADT, E, 0, 0});
+          so.insert(so.end(), ops.begin() + from, ops.begin() + to);
+          if (c < cuts.size()) { so.push_back(VmOp{PV_STT, E, 0, 0}); so.push_back(VmOp{PV_END, 0, 0, 0}); }
+          Prog sp = full;
+          sp.nops = (uint32_t)so.size(); sp.nscratch = full.nscratch + 2;
+          sp.muls_per_item = full.muls_per_item * (double)(to - from) / (double)ops.size();
+          int rc = upload(ctx, so.data(), so.size() * sizeof(VmOp), (void**)&sp.d_ops); if (rc) return rc;
+          segs.push_back(sp);
+          from = to;
+        }
+        its = ctx->seg_progs.emplace(ks, segs).first;
+      }
+      for (const Prog& sp : its->second) { int rc = run_pvm(ctx, mod_m, sp, ex3, 3, count); if (rc) return rc; }
+    }
   }
   // ---- launch 2 (m^2 context): out = (w0 + w1 m) [* mul_into] mod m^2
   int cst_m;
