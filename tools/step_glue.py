@@ -36,4 +36,5 @@ for k, v in sorted(by.items(), key=lambda kv: -kv[1]):
     if not k.startswith("library"):
         other += v
 print(f"{'all non-library kernels':86s} {other:9.3f} ms  {100 * other / span:7.3f} %")
+print(f"{'some kernel running (union of the dispatches; a context that owns the chip forks its CRT halves)':86s} {span - idle:9.3f} ms  {100 * (span - idle) / span:7.3f} %")
 print(f"{'idle between dispatches':86s} {idle:9.3f} ms  {100 * idle / span:7.3f} %")
