@@ -266,3 +266,33 @@ def test_background_randomizer_generation(engine, keys, monkeypatch):
         sch.shut_down()                                                 # collects what is still in flight
         assert not sch._pending and not sch._pool
     assert _secrets is S.secrets
+
+
+def test_segmented_pair_launch_and_forced_fork_give_the_same_residues(engine, keys):
+    """A context that shares the chip runs Alice's single-round pair launch in segments (the pair parked in the slot's table between
+    them); a context that owns it, or one in fork mode 2, runs the key holder's CRT halves side by side: the same residues as the
+    plain forms, item by item (and equal to rho^N mod N^2 on sampled rows)."""
+    from protocols.secure_comparison_amd import Paillier
+
+    sk = oracle_paillier(keys, 2048)
+    alice_p, bob_p = Paillier(sk.n, engine=engine), Paillier(sk.n, sk.p, sk.q, engine=engine)
+    rng = random.Random(5)
+    B = 24576                                    # between half a round and one round of k_pvm<4,18>: the segmented case at chip share 2
+    base = [rng.randrange(1, sk.n) for _ in range(96)]
+    rho = engine.upload(base, alice_p.mod_n.nwords).repeat(B // 96, 1).contiguous()
+    plain = alice_p.randomizer_batch(rho)
+    engine.set_chip_share(2)
+    try:
+        seg = alice_p.randomizer_batch(rho)
+    finally:
+        engine.set_chip_share(1)
+    assert torch.equal(plain, seg)
+    n2 = sk.n * sk.n
+    assert engine.download(plain[:3]) == [pow(v, sk.n, n2) for v in base[:3]]
+    small = rho[:6144].contiguous()
+    outs = []
+    for mode in (0, 2, 1):
+        engine.set_fork_mode(mode)
+        outs.append(bob_p.randomizer_batch(small))
+    engine.set_fork_mode(1)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(outs[0], plain[:6144])
