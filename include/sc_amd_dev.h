@@ -33,8 +33,11 @@ int sc_ctx_set_chip_share(sc_ctx* ctx, int contexts);
 /* Fork / join inside one call.  The p- and q-side of the key holder's CRT (sc_paillier_decrypt, sc_paillier_randomize with a secret
  * key) are independent; when a launch of the batch leaves room for a second one beside it (small batches) the q-side is queued on
  * a second stream of the context, with its own scratch arena and temporaries, and joined before the recombination.  mode 1
- * (default): automatic; 0: never (a context that already shares the GPU with another busy one, e.g. the second context that
- * computes randomizers ahead of time).  Off as well when the latency mode is 0; forced on by latency mode 2 (tests). */
+ * (default): automatic -- small batches as described (off when the latency mode is 0, forced on by latency mode 2: tests), and
+ * large ones when the context has the chip to itself (chip share 1: launches of 1.5 rounds pack when they overlap); 0: never;
+ * 2: always.  A context that shares the chip (sc_ctx_set_chip_share > 1) additionally runs a single-round pair launch -- Alice's
+ * rho^N for 32768 items: 2048 waves for 54 ms -- in four segments, so that the other context's short launches do not wait for the
+ * whole of it (environment SC_PAIR_SEGMENTS = 1 turns that off; same residues either way). */
 int sc_ctx_set_fork_mode(sc_ctx* ctx, int mode);
 /* The constants behind the automatic policies, measured once per device and process when the first secret key is created (about
  * 80 ms: full, half and one-and-a-half rounds of x^e mod p, 1024 bits, on the two-lane and on the one-lane kernel) instead of fitted
