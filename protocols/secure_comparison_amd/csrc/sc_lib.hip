@@ -161,6 +161,7 @@ struct Prog {
   double muls_per_item = 0;   // Montgomery products (full) per item
   double redcs_per_item = 0;  // reduction-only passes per item
   double sqrs_per_item = 0;   // squarings (a*a part costs L(L+1)/2 per block instead of L^2)
+  std::shared_ptr<std::vector<VmOp>> host_ops;   // the micro-ops on the host (pair programs: cut into segments on demand)
 };
 
 }  // namespace
@@ -1832,6 +1833,7 @@ int sc_modexp_shared_sq(sc_ctx* ctx, int mod_m, int mod_m2, int exp, const uint3
     Prog p;
     if (m.G == 1) nsc += 1;   // one-lane pair products park an intermediate in a spare row (the last one) of the slot's table
     p.nops = (uint32_t)ops.size(); p.nscratch = nsc; p.nconst = 4; p.muls_per_item = macs;
+    p.host_ops = std::make_shared<std::vector<VmOp>>(ops);
     int rc = upload(ctx, ops.data(), ops.size() * sizeof(VmOp), (void**)&p.d_ops); if (rc) return rc;
     rc = get_pair_consts(ctx, mod_m, &p.d_consts); if (rc) return rc;
     it1 = ctx->progs.emplace(k1, p).first;
@@ -1857,8 +1859,8 @@ int sc_modexp_shared_sq(sc_ctx* ctx, int mod_m, int mod_m2, int exp, const uint3
       auto its = ctx->seg_progs.find(ks);
       if (its == ctx->seg_progs.end()) {
         const Prog& full = it1->second;
-        std::vector<VmOp> ops(full.nops);
-        HIPCHK(ctx, hipMemcpy(ops.data(), full.d_ops, (size_t)full.nops * sizeof(VmOp), hipMemcpyDeviceToHost));
+        if (!full.host_ops) return fail(ctx, SC_ERR_HIP, "sc_modexp_shared_sq: pair program without its host copy (internal error)");
+        const std::vector<VmOp>& ops = *full.host_ops;
         // cut after a PV_MULT (the end of a window) nearest to each k / K of the op list past the table build
         std::vector<size_t> mults;
         size_t body = 0;
@@ -1881,6 +1883,7 @@ int sc_modexp_shared_sq(sc_ctx* ctx, int mod_m, int mod_m2, int exp, const uint3
           so.insert(so.end(), ops.begin() + from, ops.begin() + to);
           if (c < cuts.size()) { so.push_back(VmOp{PV_STT, E, 0, 0}); so.push_back(VmOp{PV_END, 0, 0, 0}); }
           Prog sp = full;
+          sp.host_ops.reset();
           sp.nops = (uint32_t)so.size(); sp.nscratch = full.nscratch + 2;
           sp.muls_per_item = full.muls_per_item * (double)(to - from) / (double)ops.size();
           int rc = upload(ctx, so.data(), so.size() * sizeof(VmOp), (void**)&sp.d_ops); if (rc) return rc;
