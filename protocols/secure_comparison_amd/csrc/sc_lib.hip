@@ -190,6 +190,7 @@ struct sc_ctx {
   std::map<std::pair<int, std::vector<uint32_t>>, int> const_by_value;  // (mod, residue) -> constant id
   int latency_mode = 1;                                     // sc_ctx_set_latency_mode: 0 never, 1 automatic, 2 whenever available
   int onelane_mode = 1;                                     // sc_ctx_set_onelane_mode: 0 never, 1 automatic, 2 whenever available
+  bool slot_per_item = false;                               // pair launches: a table slot per item instead of per resident wave (segments)
   int chip_share = 1;                                       // sc_ctx_set_chip_share: contexts working on this GPU at the same time
   void* comm = nullptr;                                     // RCCL communicator of this rank (sc_comm_init), one context per GPU
   int comm_rank = 0, comm_nranks = 0;
@@ -574,7 +575,9 @@ int launch_pvm_cfg(sc_ctx* ctx, const VmArgs& a) {
     occ = it->second;
   }
   uint64_t need = (a.count + NG - 1) / NG;
-  uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(need, (uint64_t)ctx->num_cu * occ));
+  // slot_per_item (segmented launches of more than one round): one wave and one table slot per group of items, so that what a
+  // segment parks in the slot's table is still there for the next one; otherwise a grid-stride loop of the resident waves
+  uint32_t grid = (uint32_t)std::max<uint64_t>(1, ctx->slot_per_item ? need : std::min<uint64_t>(need, (uint64_t)ctx->num_cu * occ));
   VmArgs args = a;
   int rc = ensure_scratch(ctx, (size_t)grid * NG * a.nscratch * (G * L) * 4, &args.scratch);
   if (rc) return rc;
@@ -1849,12 +1852,17 @@ int sc_modexp_shared_sq(sc_ctx* ctx, int mod_m, int mod_m2, int exp, const uint3
     // they wait for a quarter of that.  Multi-round launches need none of this (their waves retire a round apart).
     static const int want_segments = []{ const char* e = getenv("SC_PAIR_SEGMENTS"); return e ? atoi(e) : 4; }();
     const uint64_t wave_items = (count + (uint64_t)(64 / m.G) - 1) / (uint64_t)(64 / m.G);
-    const bool segmented = want_segments > 1 && ctx->chip_share > 1 && !ctx->stamps && m.G == 4 && m.L == 18 && ex.bits >= 512 &&
-                           wave_items <= (uint64_t)ctx->num_cu * 4 * SC_PVM_WAVES && wave_items * 2 > (uint64_t)ctx->num_cu * 4 * SC_PVM_WAVES;
+    const uint64_t resident = (uint64_t)ctx->num_cu * 4 * SC_PVM_WAVES;
+    // (4,18): Alice's rho^N of a shard, one round.  (2,18): the key holder's y^p mod p^2 of a shard, 3 x 32768 items = 1.5 rounds of
+    // 14 ms -- the short launches that close the other shard's step (recombination, steps 6 / 7) wait behind them at the end of a
+    // step, where nothing hides it: two or three segments, a table slot per item (more than one round)
+    const bool one_round = m.G == 4 && m.L == 18 && wave_items <= resident && wave_items * 2 > resident;
+    const bool few_rounds = m.G == 2 && m.L == 18 && wave_items > resident / 2 && wave_items <= 2 * resident;
+    const bool segmented = want_segments > 1 && ctx->chip_share > 1 && !ctx->stamps && ex.bits >= 512 && (one_round || few_rounds);
+    const int K = one_round ? want_segments : std::max(2, want_segments - 1);
     if (!segmented) {
       int rc = run_pvm(ctx, mod_m, it1->second, ex3, 3, count); if (rc) return rc;
     } else {
-      const int K = want_segments;
       std::string ks = k1 + ":seg" + std::to_string(K);
       auto its = ctx->seg_progs.find(ks);
       if (its == ctx->seg_progs.end()) {
@@ -1892,7 +1900,11 @@ int sc_modexp_shared_sq(sc_ctx* ctx, int mod_m, int mod_m2, int exp, const uint3
         }
         its = ctx->seg_progs.emplace(ks, segs).first;
       }
-      for (const Prog& sp : its->second) { int rc = run_pvm(ctx, mod_m, sp, ex3, 3, count); if (rc) return rc; }
+      ctx->slot_per_item = !one_round;
+      int rcs = SC_OK;
+      for (const Prog& sp : its->second) { rcs = run_pvm(ctx, mod_m, sp, ex3, 3, count); if (rcs) break; }
+      ctx->slot_per_item = false;
+      if (rcs) return rcs;
     }
   }
   // ---- launch 2 (m^2 context): out = (w0 + w1 m) [* mul_into] mod m^2

@@ -296,3 +296,12 @@ def test_segmented_pair_launch_and_forced_fork_give_the_same_residues(engine, ke
         outs.append(bob_p.randomizer_batch(small))
     engine.set_fork_mode(1)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(outs[0], plain[:6144])
+    # the key holder's y^p mod p^2 launches of a shard (more than half a round, up to two): segments with a table slot per item
+    many = rho.repeat(2, 1).contiguous()                 # 49152 numbers: 1536 waves of k_pvm<2,18>
+    whole = bob_p.randomizer_batch(many)
+    engine.set_chip_share(2)
+    try:
+        in_segments = bob_p.randomizer_batch(many)
+    finally:
+        engine.set_chip_share(1)
+    assert torch.equal(whole, in_segments) and torch.equal(whole[:B], plain)
