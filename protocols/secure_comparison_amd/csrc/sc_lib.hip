@@ -1858,8 +1858,13 @@ int sc_modexp_shared_sq(sc_ctx* ctx, int mod_m, int mod_m2, int exp, const uint3
     // step, where nothing hides it: two or three segments, a table slot per item (more than one round)
     const bool one_round = m.G == 4 && m.L == 18 && wave_items <= resident && wave_items * 2 > resident;
     const bool few_rounds = m.G == 2 && m.L == 18 && wave_items > resident / 2 && wave_items <= 2 * resident;
-    const bool segmented = want_segments > 1 && ctx->chip_share > 1 && !ctx->stamps && ex.bits >= 512 && (one_round || few_rounds);
-    const int K = one_round ? want_segments : std::max(2, want_segments - 1);
+    // The L = 14 pair twins of 1536 / 3072-bit moduli (the per-GPU share of configs[4]: Alice's launch of a shard is two rounds of
+    // 100 ms on k_pvm<8,14>, the key holder's three rounds on k_pvm<4,14>): rounds that long starve the other shard whatever their
+    // number -- 55.7 k -> 56.6 k/s with eight / three segments (for two to three 54-ms rounds of the (4,18) launch at 65536
+    // comparisons per shard the same measured 0.6 % slower: those stay whole)
+    const bool l14_rounds = m.L == 14 && (m.G == 4 || m.G == 8) && wave_items > resident / 2 && wave_items <= 3 * resident;
+    const bool segmented = want_segments > 1 && ctx->chip_share > 1 && !ctx->stamps && ex.bits >= 512 && (one_round || few_rounds || l14_rounds);
+    const int K = one_round ? want_segments : (l14_rounds && m.G == 8 ? 2 * want_segments : std::max(2, want_segments - 1));
     if (!segmented) {
       int rc = run_pvm(ctx, mod_m, it1->second, ex3, 3, count); if (rc) return rc;
     } else {
