@@ -31,7 +31,7 @@ MAX_CLOCK_HZ = 2.4e9   # MI355X peak engine clock (MI355X_MICROARCH.md)
 DEFAULT_FB_WINDOW = 20  # fixed-base window of the tables for h: 6.2 GB per GPU of 288 (21 table products per DGK randomizer instead of the 26 of
                         # window 16 / 0.66 GB: +1.0 % on the whole step in a same-box A/B, profiles/r04_ab_vs_round2_tag.txt; window_sensitivity in the line).
                         # Window 24 (17 products from an 82 GB table, built in 1.6 .. 3.6 s) is supported and was measured: +0.35 % in an alternated
-                        # A/B -- the rows' address translation eats most of the four saved products -- and the configs[1] sub-line beside the
+                        # A/B -- less than the four saved products of 71 would give; presumably row fetches that miss the address translation caches -- and the configs[1] sub-line beside the
                         # 82 GB drops from 114 k to 94 k/s (profiles/r04_fixed_base_window_24.txt): not the default
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
