@@ -1905,7 +1905,8 @@ int sc_modexp_shared_sq(sc_ctx* ctx, int mod_m, int mod_m2, int exp, const uint3
         }
         its = ctx->seg_progs.emplace(ks, segs).first;
       }
-      ctx->slot_per_item = !one_round;
+      ctx->slot_per_item = true;        // (one round: the ordinary grid already is one wave per group of items -- unless the kernel's
+                                        // occupancy on this part were lower than assumed above: asked for explicitly, never relied on)
       int rcs = SC_OK;
       for (const Prog& sp : its->second) { rcs = run_pvm(ctx, mod_m, sp, ex3, 3, count); if (rcs) break; }
       ctx->slot_per_item = false;
