@@ -476,3 +476,17 @@ def test_in_memory_transport_hands_over_public_schemes_only(world):
     assert got_d is not bob_d and got_d.secret_key is None and got_d == bob_d
     assert got_ct.scheme is got_p and got_ct.peek_value() > 0
     assert bob_p.for_wire() is got_p and got_p.for_wire() is got_p          # one public copy per scheme object
+
+
+def test_background_randomness_falls_back_to_blocking_without_a_gpu_engine(world):
+    """boot_randomness_generation(background=True) on an engine that has no second context to offer (the CPU tier's stand-in)
+    generates at once: nothing pending, the pool filled, the values rho^N mod N^2."""
+    osk, _, _, bob_p, _ = world
+    bob_p.shut_down()
+    bob_p.boot_randomness_generation(3, background=True)
+    assert not bob_p._pending and len(bob_p._pool) == 3
+    n2 = osk.n * osk.n
+    for v in list(bob_p._pool):
+        assert 0 < v < n2 and pow(v, (osk.p - 1) * (osk.q - 1), n2) == 1      # an N-th power: its order divides lambda
+    bob_p.shut_down()
+    assert not bob_p._pool
