@@ -406,7 +406,7 @@ def parse_args(argv=None):
                     "0 = automatic: 2 once every shard's widest launches still fill the chip (128 comparisons of 2048-bit keys per CU and shard, scaled by the square of the key size)")
     ap.add_argument("--side-stream", type=int, default=-1, help="run the randomizer exponentiations of a step on a second library context and stream per shard, "
                     "concurrently with the protocol's critical path (batch._AheadOfTime): 1 on, 0 off, -1 automatic (on while the batch leaves most wave slots empty: up to 32 comparisons per CU; measured +15 % at 4096, -2 % at 16384 on 256 CUs)")
-    ap.add_argument("--side-fork", type=int, default=1, help="fork mode (sc_ctx_set_fork_mode) of the second contexts: 1 = the q-side of the key holder's CRT on a second stream of that context, 0 = in sequence")
+    ap.add_argument("--side-fork", type=int, default=1, help="fork mode (sc_ctx_set_fork_mode) of the second contexts: 0 = the halves of the key holder's CRT in sequence, 1 = automatic (the q-side on a second stream of that context for small batches, and for large ones when the context has the chip to itself), 2 = always side by side")
     ap.add_argument("--fork-mode", type=int, default=1, help="fork mode of the shard contexts (sc_ctx_set_fork_mode): 0 never, 1 automatic (small batches), 2 always")
     ap.add_argument("--latency-mode", type=int, default=1, help="small-batch kernel policy (sc_ctx_set_latency_mode): 0 never, 1 automatic, 2 always")
     ap.add_argument("--onelane-mode", type=int, default=1, help="large-batch kernel policy for the 1024-bit primes (sc_ctx_set_onelane_mode): 0 never, 1 automatic, 2 always")

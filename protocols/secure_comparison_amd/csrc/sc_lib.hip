@@ -1,238 +1,23 @@
-// libsc_amd.so -- host side of the C ABI declared in include/sc_amd.h.
-// Builds the micro-programs (sc_vm.h) for each batched operation and launches the gfx950 kernels.
-#include <hip/hip_runtime.h>
-#include <dlfcn.h>
-#include <sys/random.h>
-
-#include <algorithm>
-#include <atomic>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <memory>
-#include <mutex>
-#include <string>
-#include <vector>
-
-#include "../../../include/sc_amd_dev.h"
-#include "sc_kernels.h"
-#include "sc_xgcd.h"
-#include "sc_rng.h"
+// libsc_amd.so -- host side of the C ABI declared in include/sc_amd.h and include/sc_amd_dev.h.
+// Builds the micro-programs (sc_vm.h) for each batched operation and queues the launches; the kernels themselves are instantiated in
+// the sc_launch_*.hip translation units (sc_internal.h), so this file holds no device code.
+#include "sc_internal.h"
 
 using namespace sc;
+using namespace sc_host;
 
-#ifndef SC_INV_TOP
-#define SC_INV_TOP 2048
-#endif
-
-namespace {
-
-// ------------------------------------------------------------------------------------------------
-// tiny host big-integer helpers on little-endian uint32 word vectors (setup-time only)
-// ------------------------------------------------------------------------------------------------
-typedef std::vector<uint32_t> Big;
-
-int big_bits(const Big& a) {
-  for (int i = (int)a.size() - 1; i >= 0; i--)
-    if (a[i]) return 32 * i + (32 - __builtin_clz(a[i]));
-  return 0;
-}
-int big_cmp(const Big& a, const Big& b) {  // same length
-  for (int i = (int)a.size() - 1; i >= 0; i--)
-    if (a[i] != b[i]) return a[i] > b[i] ? 1 : -1;
-  return 0;
-}
-void big_sub(Big& a, const Big& b) {  // a -= b, same length
-  uint64_t borrow = 0;
-  for (size_t i = 0; i < a.size(); i++) {
-    uint64_t v = (uint64_t)a[i] - b[i] - borrow;
-    a[i] = (uint32_t)v;
-    borrow = (v >> 32) & 1;
-  }
-}
-// a = 2a mod n  (a < n, a and n have the same length with one spare top word)
-void big_dbl_mod(Big& a, const Big& n) {
-  uint32_t carry = 0;
-  for (size_t i = 0; i < a.size(); i++) {
-    uint32_t nc = a[i] >> 31;
-    a[i] = (a[i] << 1) | carry;
-    carry = nc;
-  }
-  if (big_cmp(a, n) >= 0) big_sub(a, n);
-}
-// x * 2^k mod n
-Big big_shl_mod(const Big& x, const Big& n, int k) {
-  Big nn = n; nn.push_back(0);
-  Big v = x; v.resize(nn.size(), 0);
-  while (big_cmp(v, nn) >= 0) big_sub(v, nn);
-  for (int i = 0; i < k; i++) big_dbl_mod(v, nn);
-  v.resize(n.size());
-  return v;
-}
-Big big_trimmed_words(Big a) { while (a.size() > 1 && a.back() == 0) a.pop_back(); return a; }
-Big big_mul(const Big& a, const Big& b) {  // schoolbook product (set-up time only)
-  Big r(a.size() + b.size(), 0);
-  for (size_t i = 0; i < a.size(); i++) {
-    uint64_t carry = 0;
-    for (size_t j = 0; j < b.size(); j++) {
-      uint64_t v = (uint64_t)a[i] * b[j] + r[i + j] + carry;
-      r[i + j] = (uint32_t)v;
-      carry = v >> 32;
-    }
-    r[i + b.size()] = (uint32_t)carry;
-  }
-  return r;
-}
-// x = q * m + rem by restoring division, bit by bit (set-up time only); q has x.size() words, rem m.size() words
-void big_divmod(const Big& x, const Big& m, Big* q, Big* rem) {
-  Big r(m.size() + 1, 0), mm = m; mm.push_back(0);
-  q->assign(x.size(), 0);
-  for (int bit = 32 * (int)x.size() - 1; bit >= 0; bit--) {
-    uint32_t carry = (x[bit >> 5] >> (bit & 31)) & 1;
-    for (size_t i = 0; i < r.size(); i++) { uint32_t nc = r[i] >> 31; r[i] = (r[i] << 1) | carry; carry = nc; }
-    if (big_cmp(r, mm) >= 0) { big_sub(r, mm); (*q)[bit >> 5] |= 1u << (bit & 31); }
-  }
-  r.resize(m.size());
-  *rem = r;
-}
-std::vector<uint32_t> to_limbs(const Big& x, int S, int W) {
-  std::vector<uint32_t> out(S, 0);
-  const uint32_t mask = (1u << W) - 1;
-  for (int i = 0; i < S; i++) {
-    int bit = W * i, w0 = bit >> 5, sh = bit & 31;
-    uint64_t v = (w0 < (int)x.size()) ? x[w0] : 0;
-    if (w0 + 1 < (int)x.size()) v |= (uint64_t)x[w0 + 1] << 32;
-    out[i] = (uint32_t)(v >> sh) & mask;
-  }
-  return out;
-}
-
-struct Config { int G, L, W; bool primary; };   // primary: eligible as a modulus's own configuration (sc_mod_create)
-// ordered by capacity W*G*L; sc_mod_create takes the first one that fits.  A 28-bit-limb L = 37 family ((2,37), (4,37)) was
-// built and measured in round 1: it needs > 256 registers (one wave per SIMD plus AGPR copies) and came out 2-3 % slower
-// than (4,18) / (8,18), so it is not compiled in; the limb width stays a template parameter for such experiments.
-const Config kConfigs[] = {{1, 18, 29, true}, {2, 18, 29, true}, {2, 27, 29, true}, {4, 14, 29, true}, {4, 18, 29, true}, {4, 27, 29, true},
-                           {8, 14, 29, true}, {8, 18, 29, true}, {8, 27, 29, true}, {16, 14, 29, true}, {16, 18, 29, true}};
-// The one-lane configuration for moduli up to 1028 bits (the primes of 2048-bit Paillier / DGK keys): (1, 37) with 28-bit limbs.
-// A number lives in ONE lane, so the per-limb-step bookkeeping is paid once per number instead of once per lane of a group, the
-// operand of a squaring never leaves the registers and the modulus sits in scalar registers: 1.15 - 1.25x the (2, 18) rate
-// per number.  It needs 64 numbers per wave, i.e. large batches, and is therefore never a modulus's own configuration: the
-// shared-exponent entry points switch to an internal twin context of the same modulus when the batch fills the chip
-// (onelane_for, sc_ctx_set_onelane_mode).
-const Config kOneLane = {1, 37, 28, false};
-// configurations with a pair kernel (k_pvm): every L = 18 one, and (4,14) / (8,14) for the 1536 / 3072-bit sizes whose direct
-// configuration is L = 27 (the pair arithmetic needs the L <= 18 column bound)
-// (the one-lane (1, 37, 28) configuration has no pair kernel: measured on the MI355X its pair squarings run 3 % faster than the
-// (2, 18) ones but its pair products -- three passes over a single LDS staging area, the second area would cost the eighth wave
-// of the CU -- 2.6x a squaring instead of 1.4x, a net loss of 12 % on x^p mod p^2; the one-lane form is used where it wins:
-// the single-modulus exponentiations)
-// (8,5) / (16,5): the SMALL-BATCH pair configurations of 1024 / 2048-bit moduli (kLatencyPair below)
-inline bool pair_capable(int G, int L, int W) { return W == 29 && (L == 18 || (L == 14 && (G == 4 || G == 8)) || (L == 5 && (G == 4 || G == 8 || G == 16))); }
-// Small batches of pair exponentiations (Alice's rho^N mod N^2, the key holder's c^(p-1) mod p^2 at B = 4096) are one dependent
-// chain of ~2400 pair squarings per item, and a wave's time per squaring is its own instruction count: S limb steps of
-// (L + L/2) multiply-adds + ~7 bookkeeping instructions each, whatever the number of lanes.  When even the (2G, 9) form
-// leaves half of the SIMDs without a wave, 4x the lanes with 5 limbs each -- (16,5) for 2048-bit, (8,5) for 1024-bit moduli,
-// S = 80 / 40 limbs -- shorten every limb step from ~22 to ~15 instructions at a multiply-add density (45 %) that would be
-// wasteful on a full chip but costs nothing on an empty one.  A twin context of the same modulus, like the other twins.
-const Config kLatencyPair16 = {16, 5, 29, false}, kLatencyPair8 = {8, 5, 29, false}, kLatencyPair4 = {4, 5, 29, false};   // (4,5): 512-bit primes of 1024-bit keys
-
-struct Mod {
-  int G = 0, L = 0, W = 29, S = 0, nwords = 0, nbits = 0;
-  Big n;
-  uint32_t n0inv = 0;
-  uint32_t small_c = 0, small_cinv = 0;   // a modulus multiple M = c n (neg1_twin): c and c^-1 mod 2^W, else 0
-  uint32_t* d_ctx = nullptr;  // n | R^2 | R  limb form
-};
-struct Exp { Big e; int bits = 0; };
-struct Const { int mod = -1; uint32_t* d_limbs = nullptr; };
-// the rows of a fixed-base table are shared between contexts (sc_fbt_import): freed when the last table that uses them goes
-struct FbtRows {
-  int device = 0; uint32_t* d = nullptr; size_t bytes = 0;
-  ~FbtRows() { if (d) { (void)hipSetDevice(device); (void)hipFree(d); } }
-};
-struct Fbt { int mod = -1, window = 0, nwin = 0, exp_bits = 0; uint32_t* d_rows = nullptr; std::shared_ptr<FbtRows> rows; };
-struct Prog {
-  uint32_t nops = 0, nscratch = 1, nconst = 0;
-  VmOp* d_ops = nullptr;
-  uint32_t* d_consts = nullptr;
-  double muls_per_item = 0;   // Montgomery products (full) per item
-  double redcs_per_item = 0;  // reduction-only passes per item
-  double sqrs_per_item = 0;   // squarings (a*a part costs L(L+1)/2 per block instead of L^2)
-  std::shared_ptr<std::vector<VmOp>> host_ops;   // the micro-ops on the host (pair programs: cut into segments on demand)
-};
-
-}  // namespace
-
-struct sc_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  hipEvent_t switch_event = nullptr;   // orders the work of the previous stream before the next one (sc_ctx_set_stream)
-  int num_cu = 256;
-  std::string err;
-  int64_t last_bad_index = -1;                              // the element named by the last SC_ERR_NOT_INVERTIBLE (sc_last_bad_index)
-  std::vector<Mod> mods;
-  std::vector<Exp> exps;
-  std::vector<Const> consts;
-  std::vector<Fbt> fbts;
-  std::map<std::string, Prog> progs;
-  std::map<std::string, std::vector<Prog>> seg_progs;   // pair programs cut into segments (sc_modexp_shared_sq)
-  uint32_t* scratch = nullptr;
-  size_t scratch_bytes = 0;
-  std::vector<void*> owned;
-  double mac_counter = 0;
-  std::map<int, int> occ_cache;  // config index -> blocks per CU
-  std::map<int, std::pair<void*, size_t>> tmp;          // grow-only temporaries, reused across calls (same stream => ordered)
-  std::map<std::vector<uint32_t>, uint32_t*> nwords_cache;  // device copy of {n, (n-1)/2} for the plain-word kernels
-  std::map<int, int> kred_cache;                            // mod -> constant id of 2^(32 nwords) (wide-operand reduction)
-  std::map<std::pair<int, std::vector<uint32_t>>, int> const_by_value;  // (mod, residue) -> constant id
-  int latency_mode = 1;                                     // sc_ctx_set_latency_mode: 0 never, 1 automatic, 2 whenever available
-  int onelane_mode = 1;                                     // sc_ctx_set_onelane_mode: 0 never, 1 automatic, 2 whenever available
-  bool slot_per_item = false;                               // pair launches: a table slot per item instead of per resident wave (segments)
-  int chip_share = 1;                                       // sc_ctx_set_chip_share: contexts working on this GPU at the same time
-  void* comm = nullptr;                                     // RCCL communicator of this rank (sc_comm_init), one context per GPU
-  int comm_rank = 0, comm_nranks = 0;
-  std::map<int, int> onelane_twins;                         // mod -> context of the same modulus in the one-lane configuration
-  std::map<int, int> pair_twins;                            // mod -> context of the same modulus in a pair-capable configuration
-  std::map<int, int> neg1_twins;                            // (4,18) mod n -> context of the multiple M = c n = -1 (mod 2^29)
-  std::map<int, int> latency_pair_twins;                    // mod -> context of the same modulus in the (16,5) / (8,5) small-batch pair configuration
-  std::map<int, uint32_t*> pair_consts;                     // mod -> 4 limb arrays: pair(R^2), pair(B R) for the pair arithmetic
-  RngKey rng_key;                                           // ChaCha20 key of the context's generator (sc_rng_seed)
-  // fork / join inside one library call (AuxFork): independent halves of a small batch -- the p- and q-side of the key holder's CRT
-  // -- run on a second stream of the context with its own scratch arena and temporaries
-  hipStream_t aux_stream = nullptr;
-  hipEvent_t aux_fork = nullptr, aux_join = nullptr;
-  uint32_t* scratch_aux = nullptr;
-  size_t scratch_aux_bytes = 0;
-  bool in_aux = false;
-  // verdict words of the inversion kernel: pinned host memory the kernel writes directly (one buffer per stream of the context), so
-  // the host reads them after a stream synchronisation with no copy in between -- a device-to-host copy of a few words from pageable
-  // memory is a runtime blit kernel (__amd_rocclr_copyBuffer) that queues behind other contexts' chip-filling launches
-  int* status_host[2] = {nullptr, nullptr};
-  size_t status_cap[2] = {0, 0};
-  int fork_mode = 1;                                        // sc_ctx_set_fork_mode: 0 never fork inside a call, 1 automatic (small batches), 2 always
-  void* scheme_keys = nullptr;                              // Paillier / DGK key objects of the scheme-level entry points (sc_schemes.h)
-  bool rng_seeded = false;
-  std::atomic<uint64_t> rng_call{0};                        // generator calls since seeding: part of every keystream's nonce (atomic: two
-                                                            // host threads that ever share a context must never draw one (key, call) twice)
-  std::mutex rng_seed_mutex;                                // the lazy first seeding happens once
-  uint64_t* stamps = nullptr;                               // sc_clock_probe: the next (4,18,neg1) pair launch runs its stamping twin
-  uint32_t stamp_grid = 0;                                  // ... and reports its grid size here
-};
-
-namespace {
-
-void free_scheme_keys(void* p);   // sc_schemes.h
-
+namespace sc_host {
 int fail(sc_ctx* ctx, int code, const char* fmt, ...) {
   char buf[512];
   va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
   if (ctx) ctx->err = buf;
   return code;
 }
-#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(ctx, SC_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
+}  // namespace sc_host
+
+namespace {
+
+void free_scheme_keys(void* p);   // sc_schemes.h
 
 // every allocation selects the context's device first: the caller may have switched the thread's current device
 int dev_alloc(sc_ctx* ctx, size_t bytes, void** out) {
@@ -250,8 +35,9 @@ int upload(sc_ctx* ctx, const void* h, size_t bytes, void** out) {
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return SC_OK;
 }
+}  // namespace
 // the scratch arena of the stream the context currently launches on (its own, or the forked one's: AuxFork)
-int ensure_scratch(sc_ctx* ctx, size_t bytes, uint32_t** out) {
+int sc_host::ensure_scratch(sc_ctx* ctx, size_t bytes, uint32_t** out) {
   uint32_t*& arena = ctx->in_aux ? ctx->scratch_aux : ctx->scratch;
   size_t& have = ctx->in_aux ? ctx->scratch_aux_bytes : ctx->scratch_bytes;
   if (bytes > have) {
@@ -264,6 +50,7 @@ int ensure_scratch(sc_ctx* ctx, size_t bytes, uint32_t** out) {
   *out = arena;
   return SC_OK;
 }
+namespace {
 
 // Temporary device buffer `slot`, at least `bytes` large.  Buffers are reused by later calls: every kernel of a context
 // runs on one stream, so a later call cannot overtake an earlier one that still reads the buffer.
@@ -486,31 +273,6 @@ int finalize_prog(sc_ctx* ctx, const Mod& m, Builder& b, Prog* out) {
   return SC_OK;
 }
 
-template <int G, int L, int WB, bool NEG1 = false>
-int launch_vm_cfg(sc_ctx* ctx, const VmArgs& a, int cfg_index) {
-  auto it = ctx->occ_cache.find(cfg_index);
-  int occ;
-  if (it == ctx->occ_cache.end()) {
-    int nb = 0;
-    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_vm<G, L, WB, NEG1>, 64, 0));
-    occ = std::max(1, std::min(nb, 16));
-    ctx->occ_cache[cfg_index] = occ;
-  } else {
-    occ = it->second;
-  }
-  constexpr int NG = 64 / G;
-  uint64_t need = (a.count + NG - 1) / NG;
-  uint64_t maxb = (uint64_t)ctx->num_cu * occ;
-  uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min(need, maxb));
-  size_t scratch_bytes = (size_t)grid * NG * a.nscratch * (G * L) * 4;
-  VmArgs args = a;
-  int rc = ensure_scratch(ctx, scratch_bytes, &args.scratch);
-  if (rc) return rc;
-  hipLaunchKernelGGL((k_vm<G, L, WB, NEG1>), dim3(grid), dim3(64), 0, ctx->stream, args);
-  HIPCHK(ctx, hipGetLastError());
-  return SC_OK;
-}
-
 // Small batches: an L = 18 configuration with count * G lanes fills only part of the chip, and the run time is the latency of
 // one wave's chain of products.  The same limb arrays (S = G L limbs, identical layout in memory) can be worked on by twice
 // the lanes with half the limbs each -- (2G, 9) -- which doubles the waves and shortens the chain by 1.8x; the multiply-add
@@ -546,45 +308,13 @@ int run_vm(sc_ctx* ctx, int mod, const Prog& p, const VmExt* exts, int next, uin
   const int G = lat ? 2 * m.G : m.G, L = lat ? 9 : m.L;
   ctx->mac_counter += (double)count * ((p.muls_per_item * 2.0 + p.redcs_per_item + p.sqrs_per_item) * (double)m.S * m.S +
                                         p.sqrs_per_item * (double)G * G * L * (L + 1) / 2.0);
-  int rc = SC_ERR_UNSUPPORTED;
-  int ci = 0;
   // a (4,18) modulus = -1 (mod 2^29) -- in practice the multiple M = c n of neg1_twin -- runs the instance without the quotient multiply
-  if (G == 4 && L == 18 && m.W == 29 && m.n0inv == 1) return launch_vm_cfg<4, 18, 29, true>(ctx, a, 900);
-#define SC_CASE(GG, LL, WW) if (G == GG && L == LL && m.W == WW) rc = launch_vm_cfg<GG, LL, WW>(ctx, a, ci); ci++;
-  SC_CASE(1, 18, 29) SC_CASE(2, 18, 29) SC_CASE(2, 27, 29) SC_CASE(4, 18, 29) SC_CASE(4, 27, 29) SC_CASE(8, 18, 29) SC_CASE(8, 27, 29)
-  SC_CASE(16, 18, 29) SC_CASE(4, 14, 29) SC_CASE(8, 14, 29) SC_CASE(16, 14, 29)
-  SC_CASE(2, 9, 29) SC_CASE(4, 9, 29) SC_CASE(8, 9, 29) SC_CASE(16, 9, 29)
-  SC_CASE(1, 37, 28)
-#undef SC_CASE
+  const bool neg1 = G == 4 && L == 18 && m.W == 29 && m.n0inv == 1;
+  int rc = launch_vm_part0(ctx, G, L, m.W, neg1, a);
+  if (rc == SC_ERR_UNSUPPORTED) rc = launch_vm_part1(ctx, G, L, m.W, neg1, a);
+  if (rc == SC_ERR_UNSUPPORTED) rc = launch_vm_part2(ctx, G, L, m.W, neg1, a);
   if (rc == SC_ERR_UNSUPPORTED) return fail(ctx, rc, "no kernel configuration for G=%d L=%d", G, L);
   return rc;
-}
-
-template <int G, int L, int WB = 29, bool NEG1 = false, bool STAMP = false>
-int launch_pvm_cfg(sc_ctx* ctx, const VmArgs& a) {
-  constexpr int NG = 64 / G;
-  const int key = 1000 + 100 * L + G + (NEG1 ? 100000 : 0) + (STAMP ? 200000 : 0);
-  auto it = ctx->occ_cache.find(key);
-  int occ;
-  if (it == ctx->occ_cache.end()) {
-    int nb = 0;
-    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_pvm<G, L, WB, NEG1, STAMP>), 64, 0));
-    occ = std::max(1, std::min(nb, 16));
-    ctx->occ_cache[key] = occ;
-  } else {
-    occ = it->second;
-  }
-  uint64_t need = (a.count + NG - 1) / NG;
-  // slot_per_item (segmented launches of more than one round): one wave and one table slot per group of items, so that what a
-  // segment parks in the slot's table is still there for the next one; otherwise a grid-stride loop of the resident waves
-  uint32_t grid = (uint32_t)std::max<uint64_t>(1, ctx->slot_per_item ? need : std::min<uint64_t>(need, (uint64_t)ctx->num_cu * occ));
-  VmArgs args = a;
-  int rc = ensure_scratch(ctx, (size_t)grid * NG * a.nscratch * (G * L) * 4, &args.scratch);
-  if (rc) return rc;
-  if constexpr (STAMP) { args.stamps = ctx->stamps; ctx->stamp_grid = grid; }
-  hipLaunchKernelGGL((k_pvm<G, L, WB, NEG1, STAMP>), dim3(grid), dim3(64), 0, ctx->stream, args);
-  HIPCHK(ctx, hipGetLastError());
-  return SC_OK;
 }
 
 // pair programs: nscratch counts limb-form entries (2 per pair entry); macs = multiply-adds per item
@@ -599,30 +329,17 @@ int run_pvm(sc_ctx* ctx, int mod, const Prog& p, const VmExt* exts, int next, ui
   for (int i = 0; i < next; i++) a.ext[i] = exts[i];
   ctx->mac_counter += (double)count * p.muls_per_item;   // pair programs carry their exact multiply-add count here
   if (!pair_capable(m.G, m.L, m.W)) return fail(ctx, SC_ERR_UNSUPPORTED, "no pair kernel for G=%d L=%d", m.G, m.L);
-  if (use_latency_config(ctx, m, count) && (m.G == 1 || m.G == 2 || m.G == 4)) {
-    if (m.G == 1) return launch_pvm_cfg<2, 9>(ctx, a);      // the 512-bit primes of 1024-bit keys (BASELINE configs[0])
-    if (m.G == 2) return launch_pvm_cfg<4, 9>(ctx, a);
-    return launch_pvm_cfg<8, 9>(ctx, a);
-  }
-  if (m.L == 18) switch (m.G) {
-    case 1: return launch_pvm_cfg<1, 18>(ctx, a);
-    case 2: return launch_pvm_cfg<2, 18>(ctx, a);
-    case 4:
-      if (m.n0inv == 1 && ctx->stamps) return launch_pvm_cfg<4, 18, 29, true, true>(ctx, a);                  // sc_clock_probe's diagnostic twin
-      return m.n0inv == 1 ? launch_pvm_cfg<4, 18, 29, true>(ctx, a) : launch_pvm_cfg<4, 18>(ctx, a);   // n = -1 (mod 2^29): no quotient multiply
-    case 8: return launch_pvm_cfg<8, 18>(ctx, a);
-    case 16: return launch_pvm_cfg<16, 18>(ctx, a);
-  }
-  if (m.L == 14) switch (m.G) {
-    case 4: return m.n0inv == 1 ? launch_pvm_cfg<4, 14, 29, true>(ctx, a) : launch_pvm_cfg<4, 14>(ctx, a);
-    case 8: return m.n0inv == 1 ? launch_pvm_cfg<8, 14, 29, true>(ctx, a) : launch_pvm_cfg<8, 14>(ctx, a);
-  }
-  if (m.L == 5) switch (m.G) {
-    case 4: return launch_pvm_cfg<4, 5>(ctx, a);
-    case 8: return launch_pvm_cfg<8, 5>(ctx, a);
-    case 16: return launch_pvm_cfg<16, 5>(ctx, a);
-  }
-  return fail(ctx, SC_ERR_UNSUPPORTED, "no pair kernel for G=%d", m.G);
+  int G = m.G, L = m.L;
+  if (use_latency_config(ctx, m, count) && (m.G == 1 || m.G == 2 || m.G == 4)) { G = 2 * m.G; L = 9; }   // (2,9): the 512-bit primes of 1024-bit keys (BASELINE configs[0])
+  // n = -1 (mod 2^29): the instances without the quotient multiply exist for (4,18), (4,14), (8,14); the stamping twin of (4,18,neg1) is
+  // sc_clock_probe's diagnostic launch
+  const bool neg1 = m.n0inv == 1 && ((G == 4 && L == 18) || (L == 14 && (G == 4 || G == 8)));
+  const bool stamp = neg1 && G == 4 && L == 18 && ctx->stamps != nullptr;
+  int rc = launch_pvm_part0(ctx, G, L, neg1, stamp, a);
+  if (rc == SC_ERR_UNSUPPORTED) rc = launch_pvm_part1(ctx, G, L, neg1, stamp, a);
+  if (rc == SC_ERR_UNSUPPORTED) rc = launch_pvm_part2(ctx, G, L, neg1, stamp, a);
+  if (rc == SC_ERR_UNSUPPORTED) return fail(ctx, rc, "no pair kernel for G=%d L=%d", G, L);
+  return rc;
 }
 
 VmExt mk_ext(const void* p, uint32_t stride, uint32_t nwords, uint64_t limit = ~0ull) {
@@ -1208,8 +925,7 @@ int sc_plain_alice(sc_ctx* ctx, const uint32_t* r, const uint32_t* n_hptr, int n
   if (count == 0) return SC_OK;
   uint32_t* d_n = nullptr;
   { int rc = device_n_half(ctx, n_hptr, nw, &d_n); if (rc) return rc; }
-  hipLaunchKernelGGL(k_plain_alice, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, r, d_n, d_n + nw, nw, l, count, m1, alpha, alpha_tilde, rsmall, rshift);
-  HIPCHK(ctx, hipGetLastError());
+  if (launch_plain_alice(ctx->stream, r, d_n, d_n + nw, nw, l, count, m1, alpha, alpha_tilde, rsmall, rshift)) return fail(ctx, SC_ERR_HIP, "sc_plain_alice: launch failed");
   return SC_OK;
 }
 
@@ -1228,8 +944,7 @@ static int plain_bob_impl(sc_ctx* ctx, const uint32_t* z, const uint32_t* n_hptr
   if (count == 0) return SC_OK;
   uint32_t* d_n = nullptr;
   { int rc = device_n_half(ctx, n_hptr, nw, &d_n); if (rc) return rc; }
-  hipLaunchKernelGGL(k_plain_bob, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, z, d_n, d_n + nw, nw, l, count, beta, dbit, zeta1, zeta2, bits);
-  HIPCHK(ctx, hipGetLastError());
+  if (launch_plain_bob(ctx->stream, z, d_n, d_n + nw, nw, l, count, beta, dbit, zeta1, zeta2, bits)) return fail(ctx, SC_ERR_HIP, "sc_plain_bob: launch failed");
   return SC_OK;
 }
 
@@ -2069,8 +1784,7 @@ int sc_rng_bits(sc_ctx* ctx, int bits, uint32_t* out, uint64_t count) {
   if (ctx && bits <= 0) return fail(ctx, SC_ERR_ARG, "sc_rng_bits: bits must be positive");
   uint64_t call;
   int rc = rng_begin(ctx, count, out, "sc_rng_bits", &call); if (rc) return rc;
-  hipLaunchKernelGGL(k_rng_bits, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rng_key, call, bits, (bits + 31) / 32, out, count);
-  HIPCHK(ctx, hipGetLastError());
+  if (launch_rng_bits(ctx->stream, ctx->rng_key, call, bits, (bits + 31) / 32, out, count)) return fail(ctx, SC_ERR_HIP, "sc_rng_bits: launch failed");
   return SC_OK;
 }
 
@@ -2087,8 +1801,7 @@ int sc_rng_below(sc_ctx* ctx, const uint32_t* n_hptr, int nwords, int nonzero, u
   int rc = rng_begin(ctx, count, out, "sc_rng_below", &call); if (rc) return rc;
   uint32_t* d_n = nullptr;
   rc = device_n_half(ctx, n_hptr, nwords, &d_n); if (rc) return rc;
-  hipLaunchKernelGGL(k_rng_below, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rng_key, call, d_n, nbits, nw, nonzero ? 1 : 0, out, count);
-  HIPCHK(ctx, hipGetLastError());
+  if (launch_rng_below(ctx->stream, ctx->rng_key, call, d_n, nbits, nw, nonzero ? 1 : 0, out, count)) return fail(ctx, SC_ERR_HIP, "sc_rng_below: launch failed");
   return SC_OK;
 }
 
@@ -2096,9 +1809,7 @@ int sc_rng_coins(sc_ctx* ctx, uint64_t* out, uint64_t count) {
   if (ctx && count == 0) return SC_OK;
   uint64_t call;
   int rc = rng_begin(ctx, (count + 511) / 512, out, "sc_rng_coins", &call); if (rc) return rc;
-  const uint64_t threads = (count + 511) / 512;
-  hipLaunchKernelGGL(k_rng_coins, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rng_key, call, out, count);
-  HIPCHK(ctx, hipGetLastError());
+  if (launch_rng_coins(ctx->stream, ctx->rng_key, call, out, count)) return fail(ctx, SC_ERR_HIP, "sc_rng_coins: launch failed");
   return SC_OK;
 }
 
@@ -2107,8 +1818,7 @@ int sc_rng_permutations(sc_ctx* ctx, int k, int64_t* out, uint64_t count) {
   if (ctx && (k < 1 || k > 256)) return fail(ctx, SC_ERR_ARG, "sc_rng_permutations: 1 <= k <= 256");
   uint64_t call;
   int rc = rng_begin(ctx, count, out, "sc_rng_permutations", &call); if (rc) return rc;
-  hipLaunchKernelGGL(k_rng_perm, dim3((unsigned)((count + 63) / 64)), dim3(64), (size_t)64 * k, ctx->stream, ctx->rng_key, call, k, out, count);
-  HIPCHK(ctx, hipGetLastError());
+  if (launch_rng_perm(ctx->stream, ctx->rng_key, call, k, out, count)) return fail(ctx, SC_ERR_HIP, "sc_rng_permutations: launch failed");
   return SC_OK;
 }
 
@@ -2122,7 +1832,7 @@ int sc_peak_probe(sc_ctx* ctx, double* out_mac_per_s) {
   double best = 0;
   for (int rep = 0; rep < 4; rep++) {
     HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
-    hipLaunchKernelGGL(k_peak_probe, dim3(grid), dim3(256), 0, ctx->stream, d_out, 12345u, 67890u, iters);
+    if (launch_peak_probe(ctx->stream, grid, d_out, 12345u, 67890u, iters)) return fail(ctx, SC_ERR_HIP, "sc_peak_probe: launch failed");
     HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
     HIPCHK(ctx, hipEventSynchronize(e1));
     float ms = 0; HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));

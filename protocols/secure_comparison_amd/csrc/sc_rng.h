@@ -1,4 +1,4 @@
-// Device-side CSPRNG for the random draws of a batch (gfx950).  Included once by sc_lib.hip.
+// Device-side CSPRNG for the random draws of a batch (gfx950).  Included by sc_launch_misc.hip.
 //
 // The reference draws every random value from Python's `secrets` (SC/initiator.py:223 permutation, :250 r, :420 delta_A,
 // :512 rho_i; the scheme packages' randomizers behind .randomize()).  At 65536 comparisons per step that is ~5 KB of
@@ -15,9 +15,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "sc_vm.h"
+
 namespace sc {
 
-struct RngKey { uint32_t k[8]; };
+// (struct RngKey: sc_vm.h, shared with the host side)
 
 __device__ __forceinline__ uint32_t rotl32(uint32_t v, int s) { return __builtin_rotateleft32(v, s); }
 

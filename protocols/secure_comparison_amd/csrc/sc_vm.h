@@ -73,6 +73,8 @@ struct VmExt {
   uint64_t limit;    // flat item indices >= limit read as the integer 1 and are not written
 };
 
+struct RngKey { uint32_t k[8]; };   // ChaCha20 key of a context's generator (sc_rng.h)
+
 constexpr int VM_MAX_EXT = 8;
 constexpr int VM_MAX_CONST = 8;  // including R^2 and R
 

@@ -278,10 +278,21 @@ class _Scheme:
         return self._pool.pop()
 
     def shut_down(self) -> None:
+        """Stop the randomness generation (README.md:143-147 of the reference): what is still in flight is collected, the pools are
+        dropped, and the background twin -- a second library context holding this scheme's key material, its tables and a stream of
+        its own -- is released (a service that makes schemes per session would otherwise pile up contexts and hardware queues)."""
         while self._pending:
             self._collect_pending()
         self._pool.clear()
         self._batch_pool = None
+        bg, self._background = self._background, None
+        if bg is not None:
+            twin, stream = bg
+            stream.synchronize()
+            eng = twin._engine
+            twin._key = None
+            if eng is not None and hasattr(eng, "close"):
+                eng.close()
 
     # ---- device-resident randomizer pools for whole batches (SURVEY 8(f) item 2)
     def boot_randomness_generation_batch(self, amount: int, source: str = "device", generator=None) -> None:

@@ -435,7 +435,15 @@ def _peek_shape(mv: memoryview) -> tuple[int, tuple[int, ...]]:
     code, ndim, pad = struct.unpack_from("<BBH", mv, 4)
     if code not in _DTYPES or ndim > MAX_NDIM or pad > 4096 or len(mv) < 8 + 8 * ndim + pad:
         raise ValueError("malformed batch message header")
-    return code, tuple(struct.unpack_from(f"<{ndim}Q", mv, 8))
+    shape = tuple(struct.unpack_from(f"<{ndim}Q", mv, 8))
+    count = 1
+    for d in shape:
+        count *= d
+    # the announced shape against the bytes that arrived, BEFORE anyone sizes an array by it (a forged header announcing
+    # [255][2^20][2^10] in a 76-byte message would otherwise make the receiver try a terabyte allocation)
+    if count * _DTYPES[code][1].itemsize != len(mv) - 8 - 8 * ndim - pad:
+        raise ValueError(f"batch message announces shape {shape} but carries {len(mv) - 8 - 8 * ndim - pad} payload bytes")
+    return code, shape
 
 
 def unpack_many(buf: Any, device: torch.device | str = "cpu", expect: int | None = None, planes_of_one: bool = False) -> list[torch.Tensor]:

@@ -274,3 +274,32 @@ def test_kernel_written_message_layout_and_padding(monkeypatch):
     struct.pack_into("<H", mv, 4 + 8 + 6, 3)                                   # another padding: the payload size no longer matches
     with pytest.raises(ValueError):
         wire.unpack_many(bytes(mv), "cpu")
+
+
+def test_forged_plane_header_is_refused_before_anything_is_allocated():
+    """Round-4 advice: with planes_of_one the receiver sized ONE array for [d] and the planes [beta_i] from the two announced shapes
+    before either payload had been compared with its header -- a 76-byte message announcing [2^20][2^10] and [255][2^20][2^10] made
+    it try a terabyte allocation (RuntimeError, or a real 200 GB array on the GPU).  The announced shape is now held against the
+    bytes that arrived first: ValueError, in both forms, and a well-formed pair still joins."""
+    import struct
+
+    from protocols.secure_comparison_amd import wire
+
+    def array_msg(shape, payload=b""):
+        return wire.MAGIC + struct.pack("<BBH", 0, len(shape), 0) + struct.pack(f"<{len(shape)}Q", *shape) + payload
+
+    a, b = array_msg((1 << 20, 1 << 10)), array_msg((255, 1 << 20, 1 << 10))
+    forged = struct.pack("<I", 2) + struct.pack("<Q", len(a)) + a + struct.pack("<Q", len(b)) + b
+    assert len(forged) < 100
+    for planes in (True, False):
+        with pytest.raises(ValueError, match="announces shape"):
+            wire.unpack_many(forged, "cpu", planes_of_one=planes)
+    # only the second header lies: still refused before the joint array exists
+    d = torch.arange(6, dtype=torch.int32).reshape(2, 3)
+    good_a = bytes(wire.pack_tensor(d))
+    lying = struct.pack("<I", 2) + struct.pack("<Q", len(good_a)) + good_a + struct.pack("<Q", len(array_msg((60000, 2, 3)))) + array_msg((60000, 2, 3))
+    with pytest.raises(ValueError, match="announces shape"):
+        wire.unpack_many(lying, "cpu", planes_of_one=True)
+    planes_t = torch.arange(24, dtype=torch.int32).reshape(4, 2, 3)
+    got = wire.unpack_many(bytes(wire.pack_many(d, planes_t)), "cpu", expect=2, planes_of_one=True)
+    assert torch.equal(got[0], d) and torch.equal(got[1], planes_t) and got[1].data_ptr() == got[0].data_ptr() + 24
