@@ -1,0 +1,113 @@
+"""Concurrent single comparisons as batch launches.
+
+The reference's call shape is ONE comparison per `perform_secure_comparison` call, concurrency by asyncio sessions of one
+Initiator / KeyHolder pair whose messages are kept apart by the session number
+(/root/reference/src/tno/mpc/protocols/secure_comparison/initiator.py:69-175, :86-87; test/unit/test_secure_comparison.py:804-835).
+On the GPU a lone comparison is a chain of dependent launches on an otherwise idle chip (8.9 ms): N concurrent sessions
+that each walk that chain cost N times as much, although the chip could take thousands of them in the same launches.
+
+`StepCoalescer` closes that gap without changing the call shape: a session hands each of its steps to the coalescer of its player
+object and awaits the result; requests of the same step that arrive within the same turn of the event loop (plus an optional
+linger, or until `max_batch` are waiting) are executed as ONE call of the batch entry points (sc_initiator_step1 / _step4 /
+_step67, sc_keyholder_step2_4b / _step4j_5) and the rows handed back to their sessions.  Every session still makes its own random
+draws, in its own task, in the order the single path makes them -- so its messages are the same integers as in an uncoalesced run
+with the same draws (tests/test_gpu_round5.py, tests/test_coalesce_cpu.py).
+"""
+from __future__ import annotations
+
+import asyncio
+from typing import Any, Callable, Sequence
+
+
+class _Queue:
+    __slots__ = ("items", "futures", "run", "armed", "seen", "lingered")
+
+    def __init__(self) -> None:
+        self.items: list = []
+        self.futures: list[asyncio.Future] = []
+        self.run: Callable[[list], Sequence] | None = None
+        self.armed = False
+        self.seen = 0
+        self.lingered = False
+
+
+class StepCoalescer:
+    """Gathers the step requests of the concurrent sessions of ONE player object.
+
+    max_batch: a queue that reaches this many requests is executed at once.  linger_s: after the first quiet turn of the event loop
+    wait this much longer for stragglers (0: execute at once; a transport between two hosts delivers the messages of concurrent
+    sessions microseconds to milliseconds apart).  The batched call itself runs synchronously on the event loop's thread, like every
+    GPU call of the single path."""
+
+    def __init__(self, max_batch: int = 4096, linger_s: float = 0.0) -> None:
+        self.max_batch = max(1, int(max_batch))
+        self.linger_s = float(linger_s)
+        self._queues: dict[str, _Queue] = {}
+        self.stats = {"calls": 0, "items": 0, "largest": 0, "fallbacks": 0}
+
+    async def submit(self, kind: str, run: Callable[[list], Sequence], item: Any) -> Any:
+        """Queue `item` for the step `kind`; `run(items)` makes ONE batched call for a list of such items and returns one result per
+        item, in order.  Returns this item's result (or raises what its own execution raised)."""
+        loop = asyncio.get_running_loop()
+        q = self._queues.get(kind)
+        if q is None:
+            q = self._queues[kind] = _Queue()
+        if q.futures and q.futures[0].get_loop() is not loop:       # a player object moved to another event loop with requests pending
+            raise RuntimeError("a step coalescer serves one event loop at a time")
+        fut = loop.create_future()
+        q.items.append(item)
+        q.futures.append(fut)
+        q.run = run
+        if len(q.items) >= self.max_batch:
+            self._flush(kind)
+        elif not q.armed:
+            q.armed, q.seen, q.lingered = True, 0, False
+            loop.call_soon(self._tick, kind, loop)
+        return await fut
+
+    def _tick(self, kind: str, loop: asyncio.AbstractEventLoop) -> None:
+        q = self._queues.get(kind)
+        if q is None or not q.armed:
+            return
+        if len(q.items) != q.seen:                 # the queue grew during the last turn: sessions are still arriving
+            q.seen = len(q.items)
+            loop.call_soon(self._tick, kind, loop)
+        elif self.linger_s > 0 and not q.lingered:
+            q.lingered = True
+            loop.call_later(self.linger_s, self._tick, kind, loop)
+        else:
+            self._flush(kind)
+
+    def _flush(self, kind: str) -> None:
+        q = self._queues.pop(kind, None)
+        if q is None or not q.items:
+            return
+        items, futures, run = q.items, q.futures, q.run
+        self.stats["calls"] += 1
+        self.stats["items"] += len(items)
+        self.stats["largest"] = max(self.stats["largest"], len(items))
+        try:
+            results = list(run(items))
+            if len(results) != len(items):
+                raise RuntimeError(f"batched step {kind!r} returned {len(results)} results for {len(items)} requests")
+            outcomes = [(True, r) for r in results]
+        except Exception as exc:  # noqa: BLE001 -- handed to the session(s) it belongs to
+            if len(items) == 1:
+                outcomes = [(False, exc)]
+            else:
+                # one session's bad input (a non-invertible ciphertext, a malformed value) must not fail its neighbours: every request
+                # on its own, each session gets its own outcome
+                self.stats["fallbacks"] += 1
+                outcomes = []
+                for it in items:
+                    try:
+                        outcomes.append((True, list(run([it]))[0]))
+                    except Exception as one:  # noqa: BLE001
+                        outcomes.append((False, one))
+        for fut, (ok, value) in zip(futures, outcomes):
+            if fut.done():                          # the session was cancelled while it waited
+                continue
+            if ok:
+                fut.set_result(value)
+            else:
+                fut.set_exception(value)

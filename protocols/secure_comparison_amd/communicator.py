@@ -22,33 +22,63 @@ class Communicator(Protocol):
         """Wait for the message labelled `msg_id` from `party_id`."""
 
 
-class InMemoryCommunicator:
-    """Shared-mailbox transport for two players living in one event loop."""
+_WAITERS = "\0waiting receivers"    # reserved mailbox key: msg_id -> future of a receiver that arrived before its message
 
-    def __init__(self, mailbox: dict[str, Any] | None = None, max_polls: int = 1_000_000, device_tensors: bool = True) -> None:
+
+class InMemoryCommunicator:
+    """Shared-mailbox transport for two players living in one process.  Event-driven: a receiver that arrives before its message
+    leaves a future in the mailbox and the sender resolves it -- no polling, so a thousand concurrent sessions waiting for
+    their peers cost the event loop nothing (round 4 polled with `asyncio.sleep(0)`: every waiting session woke on every turn
+    of the loop)."""
+
+    def __init__(self, mailbox: dict[str, Any] | None = None, max_polls: int = 1_000_000, device_tensors: bool = True,
+                 timeout_s: float | None = 600.0) -> None:
         self.mailbox: dict[str, Any] = {} if mailbox is None else mailbox
-        self.max_polls = max_polls
+        self.max_polls = max_polls                   # (kept for callers of the polling form; unused)
+        self.timeout_s = timeout_s
         # Both endpoints live in one process: a batch message may carry the device arrays themselves (wire.DeviceArrays) instead
         # of bytes.  False makes the batch protocol serialize as it would for a real transport (one pinned host buffer).
         self.device_tensors = device_tensors
 
     def peer(self) -> "InMemoryCommunicator":
         """A second endpoint on the same mailbox (hand it to the other player)."""
-        return InMemoryCommunicator(self.mailbox, self.max_polls, self.device_tensors)
+        return InMemoryCommunicator(self.mailbox, self.max_polls, self.device_tensors, self.timeout_s)
 
     async def send(self, party_id: str, message: Any, msg_id: str) -> None:
         if msg_id in self.mailbox:
             raise RuntimeError(f"message id {msg_id!r} is already pending")
-        self.mailbox[msg_id] = _as_on_wire(message)
+        payload = _as_on_wire(message)
+        waiters = self.mailbox.get(_WAITERS)
+        fut = waiters.pop(msg_id, None) if waiters else None
+        if waiters is not None and not waiters:
+            del self.mailbox[_WAITERS]
+        if fut is None or fut.done():                # nobody waits yet (or the receiver gave up): the message waits
+            self.mailbox[msg_id] = payload
+            return
+        loop = fut.get_loop()
+        if loop is asyncio.get_running_loop():
+            fut.set_result(payload)
+        else:                                        # the receiver lives on another thread's event loop
+            loop.call_soon_threadsafe(lambda: fut.done() or fut.set_result(payload))
 
     async def recv(self, party_id: str, msg_id: str) -> Any:
-        for i in range(self.max_polls):
-            if msg_id in self.mailbox:
-                return self.mailbox.pop(msg_id)
-            # a peer that is in the middle of a long GPU step (or whose message is still draining over PCIe) is not polled in a
-            # tight loop for its whole duration
-            await asyncio.sleep(0 if i < 2000 else 0.0002)
-        raise TimeoutError(f"no message {msg_id!r} from {party_id!r}")
+        if msg_id in self.mailbox:
+            return self.mailbox.pop(msg_id)
+        fut = asyncio.get_running_loop().create_future()
+        waiters = self.mailbox.setdefault(_WAITERS, {})
+        if msg_id in waiters:
+            raise RuntimeError(f"two receivers wait for message {msg_id!r}")
+        waiters[msg_id] = fut
+        try:
+            return await (fut if self.timeout_s is None else asyncio.wait_for(fut, self.timeout_s))
+        except asyncio.TimeoutError:
+            raise TimeoutError(f"no message {msg_id!r} from {party_id!r}") from None
+        finally:
+            left = self.mailbox.get(_WAITERS)
+            if left is not None and left.get(msg_id) is fut:
+                del left[msg_id]
+                if not left:
+                    del self.mailbox[_WAITERS]
 
 
 def _as_on_wire(message: Any) -> Any:

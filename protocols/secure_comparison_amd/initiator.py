@@ -40,6 +40,12 @@ class Initiator:
     # perform_secure_comparison runs Alice's steps as three library calls on one-element batches (True) or, like the reference's
     # body, step by step through the ciphertext operator algebra (False: one launch per operator).  Same ciphertexts either way.
     fuse_steps = True
+    # Concurrent perform_secure_comparison sessions of one Initiator hand their steps to a coalescer (coalesce.StepCoalescer): requests
+    # of the same step that arrive in the same turn of the event loop run as ONE call of the batch entry points.  A lone session
+    # takes the same path as a batch of one; False restores one library call per session and step.
+    coalesce_sessions = True
+    coalesce_max_batch = 4096
+    coalesce_linger_s = 0.0
 
     def __init__(self, l_maximum_bit_length: int, communicator: Communicator | None = None, other_party: str = "",
                  scheme_paillier: Paillier | None = None, scheme_dgk: DGK | None = None, session_id: int = 0) -> None:
@@ -70,6 +76,8 @@ class Initiator:
         self.session_id += 1
         sid = self.session_id
         await self.receive_encryption_schemes(sid)
+        if self.fuse_steps and self.coalesce_sessions:
+            return await self._perform_coalesced(x, y, sid)
         self._start_randomness_generation()
         l = self.l_maximum_bit_length
         pai, dgk = self.scheme_paillier, self.scheme_dgk
@@ -135,6 +143,91 @@ class Initiator:
         three = e.upload([zeta_1_enc.get_value(), zeta_2_enc.get_value(), delta_b_enc.get_value()], 2 * nw)
         res = Initiator.step_6_7_batch(e.upload_u64([delta_a]), three[2:3], three[0:1], three[1:2], plain, l, pai)
         return PaillierCiphertext(e.download(res)[0], pai)
+
+    # ------------------------------------------------------------------ concurrent sessions, coalesced into batch launches
+    def _coalescer(self):
+        from .coalesce import StepCoalescer
+
+        co = self.__dict__.get("_step_coalescer")
+        if co is None or co.max_batch != self.coalesce_max_batch or co.linger_s != self.coalesce_linger_s:
+            co = self.__dict__["_step_coalescer"] = StepCoalescer(self.coalesce_max_batch, self.coalesce_linger_s)
+        return co
+
+    async def _perform_coalesced(self, x: PaillierCiphertext | float, y: PaillierCiphertext | float, sid: int) -> PaillierCiphertext:
+        """One session of SC/initiator.py:69-175 whose steps run inside the batch launches it shares with the other sessions in
+        flight.  The session draws what the single path draws, where it draws it: the inputs of its 1 + (l + 1) randomizers
+        (_start_randomness_generation, :205-210), r (:250), delta_A (:420), rho_i (:512), the shuffle (:223); the k-th
+        `.randomize()` takes the randomizer the pool would have handed it (the pool is used from its end).  Plaintext inputs are
+        encrypted inside the step-1 launch (the unrandomized encryption 1 + mN of `unsafe_encrypt`, :93-102)."""
+        pai, dgk, l = self.scheme_paillier, self.scheme_dgk, self.l_maximum_bit_length
+        n, u = pai.public_key.n, dgk.public_key.u
+        co = self._coalescer()
+        rho_z = 1 + secrets.randbelow(n - 1)                                       # boot_randomness_generation(1): [[z]].randomize() (:109)
+        r_dgk = [secrets.randbits(dgk.randomizer_bits) for _ in range(l + 1)]      # boot_randomness_generation(l + 1) (:153-154)
+        # (ciphertext value, None) or (None, encoded plaintext): plaintext inputs are encrypted inside the batched call
+        xv = (x.get_value(), None) if isinstance(x, PaillierCiphertext) else (None, pai._encode(x))
+        yv = (y.get_value(), None) if isinstance(y, PaillierCiphertext) else (None, pai._encode(y))
+        assert (1 << (l + 2)) < n // 2
+        r = secrets.randbelow(n)                                                   # step 1 (:250)
+        z = await co.submit("step_1", self._run_step_1, (xv, yv, r, rho_z))
+        await self.communicator.send(self.other_party, PaillierCiphertext(z, pai, fresh=True), msg_id=f"step_1_session_{sid}")
+        d_enc, beta_is_enc = await self.communicator.recv(self.other_party, msg_id=f"step_4b_session_{sid}")
+        if len(beta_is_enc) != l:
+            raise ValueError(f"received {len(beta_is_enc)} encrypted bits, expected {l}")
+        assert 0 <= r < n                                                          # step 4c (:286-288)
+        _, delta_a = Initiator.step_4g()                                           # (:420)
+        rhos = [secrets.randbelow(u - 1) + 1 for _ in range(l + 1)]                 # step 4i (:512)
+        perm = Initiator.shuffle(list(range(l + 1)))                                # (:516): output k takes the blinded c at perm[k]
+        exps = [0] * (l + 1)
+        for k, src in enumerate(perm):
+            exps[src] = r_dgk[l - k]          # the k-th c.randomize() (:153-154) pops the pool's last entry: draw l - k, applied to the item that lands at output k
+        planes = [d_enc.get_value()] + [b.get_value() for b in beta_is_enc]
+        c = await co.submit("step_4", self._run_step_4, (planes, r, delta_a, rhos, perm, exps))
+        await self.communicator.send(self.other_party, [DGKCiphertext(v, dgk, fresh=True) for v in c], msg_id=f"step_4i_session_{sid}")
+        zeta_1_enc, zeta_2_enc, delta_b_enc = await self.communicator.recv(self.other_party, msg_id=f"step_5_session_{sid}")
+        res = await co.submit("step_6_7", self._run_step_6_7, (zeta_1_enc.get_value(), zeta_2_enc.get_value(), delta_b_enc.get_value(), r, delta_a))
+        return PaillierCiphertext(res, pai)
+
+    def _alice_plain(self, rs: list[int]) -> AlicePlain:
+        """Alice's plaintext-side values (SC/initiator.py:270, :289, :373, :559-562) for the blinding values `rs`: she knows r, so
+        they are host integers uploaded with the batch -- the sessions of a later step need not be those of an earlier one."""
+        pai, l = self.scheme_paillier, self.l_maximum_bit_length
+        e, n, nw = pai.engine, pai.public_key.n, pai.mod_n.nwords
+        mask, half = (1 << l) - 1, (n - 1) // 2
+        return AlicePlain(e.upload(rs, nw), e.upload_u64([r & mask for r in rs]), e.upload_u64([(r - n) & mask for r in rs]),
+                          e.upload_u64([int(r < half) for r in rs]), e.upload([r >> l for r in rs], nw))
+
+    def _run_step_1(self, items: list) -> list[int]:
+        """Step 1 + `.randomize()` of K sessions: one sc_initiator_step1 call (the pair exponentiation rho_z^N fused in)."""
+        pai, l = self.scheme_paillier, self.l_maximum_bit_length
+        e, nw = pai.engine, pai.mod_n.nwords
+        xy = e.upload([(it[c][0] or 0) for c in (0, 1) for it in items], 2 * nw)          # rows 0 .. K-1: [[x]], K .. 2K-1: [[y]]
+        plain = [(c * len(items) + b, it[c][1]) for c in (0, 1) for b, it in enumerate(items) if it[c][0] is None]
+        if plain:                                     # unsafe_encrypt of the plaintext inputs (SC/initiator.py:93-102), one launch
+            rows = torch.tensor([i for i, _ in plain], dtype=torch.int64, device=xy.device)
+            xy[rows] = pai.encrypt_raw_batch(e.upload([m for _, m in plain], nw))
+        z, _ = Initiator.step_1_batch(xy[:len(items)], xy[len(items):], l, pai, e.upload([it[2] for it in items], nw), e.upload([it[3] for it in items], nw))
+        return e.download(z)
+
+    def _run_step_4(self, items: list) -> list[list[int]]:
+        """Steps 4c .. 4i + the l + 1 `.randomize()` of K sessions: one sc_initiator_step4 call on bit-major planes [l+1][K]."""
+        dgk, l = self.scheme_dgk, self.l_maximum_bit_length
+        e, nd, k = dgk.engine, dgk.mod_n.nwords, len(items)
+        ew, er = (dgk.public_key.u.bit_length() + 31) // 32, (dgk.randomizer_bits + 31) // 32
+        major = lambda col, w: e.upload([it[col][j] for j in range(l + 1) for it in items], w).reshape(l + 1, k, w)   # noqa: E731
+        planes = major(0, nd)
+        c, _ = Initiator.step_4_batch(planes[0], planes[1:], self._alice_plain([it[1] for it in items]), e.upload_u64([it[2] for it in items]), dgk,
+                                      major(3, ew), e.upload_u64([v for it in items for v in it[4]]).reshape(k, l + 1), major(5, er))
+        flat = e.download(c.reshape((l + 1) * k, nd))
+        return [[flat[j * k + b] for j in range(l + 1)] for b in range(k)]
+
+    def _run_step_6_7(self, items: list) -> list[int]:
+        """Steps 6 and 7 of K sessions: one sc_initiator_step67 call."""
+        pai, l = self.scheme_paillier, self.l_maximum_bit_length
+        e, nw = pai.engine, pai.mod_n.nwords
+        up = lambda col: e.upload([it[col] for it in items], 2 * nw)   # noqa: E731
+        res = Initiator.step_6_7_batch(e.upload_u64([it[4] for it in items]), up(2), up(0), up(1), self._alice_plain([it[3] for it in items]), l, pai)
+        return e.download(res)
 
     async def perform_secure_comparison_batch(self, x_enc: torch.Tensor, y_enc: torch.Tensor, draws=None,
                                               source: str = "device", engine=None, generator=None, chunks: int = 1) -> torch.Tensor:

@@ -264,6 +264,10 @@ class _Scheme:
         second context to be had (schemes without a background twin, the CPU test tier's stand-in engine)."""
         return None
 
+    def _launch_randomness_values(self, values: list[int]):
+        """The same for randomizer inputs the caller drew itself (coalesced sessions draw their own)."""
+        return None
+
     def _collect_pending(self) -> None:
         t, ev, twin = self._pending.pop(0)
         ev.synchronize()
@@ -454,8 +458,16 @@ class Paillier(_Scheme):
     def _launch_randomness(self, amount: int):
         from .engine import Engine
 
+        if not isinstance(self.engine, Engine):      # the CPU test tier's stand-in engine: nothing to overlap (and nothing drawn here)
+            return None
+        n = self.public_key.n
+        return self._launch_randomness_values([1 + secrets.randbelow(n - 1) for _ in range(amount)])      # drawn now, in the caller's order
+
+    def _launch_randomness_values(self, values: list[int]):
+        from .engine import Engine
+
         eng = self.engine
-        if not isinstance(eng, Engine):              # the CPU test tier's stand-in engine: nothing to overlap
+        if not isinstance(eng, Engine):
             return None
         if self._background is None:
             sk = self.secret_key
@@ -463,8 +475,6 @@ class Paillier(_Scheme):
                             use_crt=self.use_crt, use_pairs=self.use_pairs, precision=self.precision)
             self._background = (twin, torch.cuda.Stream(device=eng.device))
         twin, stream = self._background
-        n = self.public_key.n
-        values = [1 + secrets.randbelow(n - 1) for _ in range(amount)]      # drawn now, in the caller's order
         stream.wait_stream(torch.cuda.current_stream(eng.device))
         with torch.cuda.stream(stream):
             t = twin.randomizer_batch(twin.engine.upload(values, twin.mod_n.nwords))

@@ -37,9 +37,9 @@ def _oracle_rows(engine, idx, l, sk, dgk, x_enc, y_enc, draws):
 
 
 @pytest.mark.parametrize("pbits, dname, B, l", [
-    (2048, "dgk_2048_l32", 131072, 32),      # configs[3]: 1M comparisons over 8 GPUs -> 131072 per GPU
-    (3072, "dgk_2048_l64", 32768, 64),       # configs[4]: 262144 over 8 GPUs -> 32768 per GPU; DGK size unspecified there:
-    (3072, "dgk_3072_l64", 32768, 64),       #             2048-bit (the reference's default, SC/keyholder.py:140) and 3072-bit
+    # (configs[3]'s share of 131072 and configs[4]'s with the 2048-bit DGK key run with two concurrent shards, as bench.py runs
+    #  them, in test_gpu_round3.py::test_the_configuration_bench_times -- under the oracle as well)
+    (3072, "dgk_3072_l64", 32768, 64),       # configs[4]: 262144 over 8 GPUs -> 32768 per GPU, DGK size unspecified there: the 3072-bit variant, one stream
 ])
 def test_per_gpu_shares_of_the_eight_gpu_configs_full_size(engine, keys, pbits, dname, B, l):
     """Full-size per-GPU shares (scratch arena, parking buffer, inversion-tree depth, 67-bit rho at l = 64): Dec(result) ==

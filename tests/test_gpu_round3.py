@@ -96,19 +96,26 @@ def test_modinv_refuses_in_place(engine):
         engine.modinv(mod, big[:100], out=big[28:128])
 
 
-def test_the_configuration_bench_times(engine, keys):
-    """BASELINE configs[2] exactly as bench.py runs it: B = 65536, l = 32, 2048/2048-bit keys, TWO concurrent shards (one
-    library context, stream and host thread each, chip_share = 2 moving the one-lane threshold), fixed-base tables built once
-    and imported by the second context, step-4i shuffle on.  Dec(result) == [x <= y] for all rows, and 20 sampled rows -- first
-    and last of each shard, both sides of the shard cut, a partially filled wave -- bit-exact against the oracle."""
+@pytest.mark.parametrize("pbits, dname, B, l", [
+    (2048, "dgk_2048_l32", 65536, 32),       # BASELINE configs[2]: the headline
+    (2048, "dgk_2048_l32", 131072, 32),      # per-GPU share of configs[3]: two to three rounds per pair launch, those stay whole
+    (3072, "dgk_2048_l64", 32768, 64),       # per-GPU share of configs[4]: the L = 14 pair twins in eight / three segments (l14_rounds)
+])
+def test_the_configuration_bench_times(engine, keys, pbits, dname, B, l):
+    """The shapes bench.py times, exactly as it runs them (the headline and the two `other_configs` / per-GPU shares): TWO concurrent
+    shards (one library context, stream and host thread each, chip_share = 2 moving the one-lane threshold and cutting the long
+    pair launches into segments), fixed-base tables built once and imported by the second context, step-4i shuffle on.
+    Dec(result) == [x <= y] for all rows, and 20 sampled rows -- first and last of each shard, both sides of the shard cut, a
+    partially filled wave -- bit-exact against the ORACLE (round 4 held the configs[3] / [4] shares with two shards to the decrypt
+    property only)."""
     import bench
     from protocols.secure_comparison_amd import DGK, Paillier
     from protocols.secure_comparison_amd.batch import ConcurrentShards, PartySet, split_draws
     from protocols.secure_comparison_amd.distributed import shard_bounds
     from protocols.secure_comparison_amd.engine import Engine
 
-    sk, dgk = oracle_paillier(keys, 2048), oracle_dgk(keys, "dgk_2048_l32")
-    B, l, rbits, window = 65536, 32, 400, bench.DEFAULT_FB_WINDOW
+    sk, dgk = oracle_paillier(keys, pbits), oracle_dgk(keys, dname)
+    rbits, window = 400, min(bench.DEFAULT_FB_WINDOW, 20)
     engines = [Engine(), Engine()]
     sets = []
     for i, e in enumerate(engines):
@@ -135,8 +142,10 @@ def test_the_configuration_bench_times(engine, keys):
     cut = bounds[0][1]
     idx = [0, 1, 7, 15, 16, 63, 64, 1000, cut - 65, cut - 2, cut - 1, cut, cut + 1, cut + 17, cut + 4096, B - 4097, B - 66, B - 3, B - 2, B - 1]
     assert engines[0].download(res[torch.tensor(idx, device=res.device)]) == _oracle_rows(engines[0], idx, l, sk, dgk, x_enc, y_enc, draws)
+    del sets, shard_inputs, runner
     for e in engines:
         e.close()
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("device_tensors", [True, False])

@@ -1,0 +1,83 @@
+"""GPU tests added in round 5: the segmented pair launches of 3072-bit keys (the L = 14 twins) item by item against the whole
+launch and against Python's pow; concurrent single comparisons coalesced into batch launches, every message against the
+uncoalesced run; the new interpreter forms of the round."""
+import asyncio
+import contextvars
+import os
+import random
+import sys
+
+import pytest
+import torch
+
+from conftest import oracle_dgk, oracle_paillier
+
+pytestmark = pytest.mark.gpu
+
+
+def test_segmented_pair_launches_of_3072_bit_keys(engine, keys):
+    """Round 4 cut the long pair launches of a context that shares the chip into segments also for the L = 14 twins of 1536 / 3072-bit
+    moduli (`l14_rounds`, sc_modexp_shared_sq: Alice's rho^N mod N^2 on k_pvm<8,14> in eight segments, the key holder's y^p mod p^2
+    on k_pvm<4,14> in three, a table slot per item) and covered them by a decrypt property only.  Here: segmented == whole, item by
+    item, and == pow(rho, N, N^2) on sampled rows, on both kernels, with batch sizes inside the branch's window (more than half a
+    round of resident waves)."""
+    from protocols.secure_comparison_amd import Paillier
+
+    sk = oracle_paillier(keys, 3072)
+    alice_p, bob_p = Paillier(sk.n, engine=engine), Paillier(sk.n, sk.p, sk.q, engine=engine)
+    rng = random.Random(14)
+    n2 = sk.n * sk.n
+    base = [rng.randrange(1, sk.n) for _ in range(48)] + [1, sk.n - 1]
+    engine.set_latency_mode(1)
+    try:
+        for scheme, count in ((alice_p, 12000), (bob_p, 24000)):       # ragged on purpose: the last wave of either launch is partly filled
+            rho = engine.upload(base, scheme.mod_n.nwords).repeat(count // len(base), 1).contiguous()
+            whole = scheme.randomizer_batch(rho)
+            engine.set_chip_share(2)
+            try:
+                seg = scheme.randomizer_batch(rho)
+            finally:
+                engine.set_chip_share(1)
+            assert torch.equal(whole, seg)
+            rows = [0, 1, 7, 48, 49, len(base), rho.shape[0] - 51, rho.shape[0] - 1]
+            assert engine.download(seg[torch.tensor(rows, device=seg.device)]) == [pow(base[i % len(base)], sk.n, n2) for i in rows]
+    finally:
+        engine.set_latency_mode(0)
+
+
+@pytest.mark.parametrize("pbits, dname, l, sessions", [(1024, "dgk_1024_l16", 16, 256), (2048, "dgk_2048_l32", 32, 48)])
+def test_concurrent_sessions_are_coalesced_into_batch_launches(engine, keys, pbits, dname, l, sessions):
+    """The reference's primary usage -- many concurrent single comparisons on one Initiator / KeyHolder pair (SC/initiator.py:69-175,
+    :86-87; test/unit/test_secure_comparison.py:804-835) -- through the session coalescer: `sessions` concurrent
+    perform_secure_comparison(x_i, y_i) tasks, strict warnings, run as a handful of batch launches, and EVERY message of every
+    session equals what that session sends when it runs alone through the uncoalesced one-element path with the same random stream
+    (which tests/test_gpu_round4.py holds against the operator path and the oracle).  All results decrypt to x_i <= y_i."""
+    sys.path.insert(0, os.path.dirname(__file__))
+    from _coalesce_harness import run_sessions
+    from protocols.secure_comparison_amd import DGK, Paillier
+
+    sk, dgk = oracle_paillier(keys, pbits), oracle_dgk(keys, dname)
+    bob_p = Paillier(sk.n, sk.p, sk.q, engine=engine)
+    bob_d = DGK(dgk.n, dgk.g, dgk.h, dgk.u, dgk.t, dgk.p, dgk.q, dgk.v_p, dgk.v_q, engine=engine, randomizer_bits=400)
+    rng = random.Random(sessions)
+    pairs = [(23, 42), (42, 23), (7, 7), (-5, -5), (-9, 4)] + [(rng.randrange(1 << l), rng.randrange(1 << l)) for _ in range(sessions - 5)]
+    pairs[9] = (pairs[9][0], pairs[9][0] + 1)
+    engine.set_latency_mode(1)
+    try:
+        co_res, co_sent, stats = run_sessions(pairs, l, bob_p, bob_d, coalesce=True)
+        check = list(range(sessions)) if sessions <= 64 else sorted(set([0, 1, 2, 3, 4, 9, sessions - 1] + [rng.randrange(sessions) for _ in range(24)]))
+        un_res, un_sent, _ = run_sessions(pairs, l, bob_p, bob_d, coalesce=False)
+    finally:
+        engine.set_latency_mode(0)
+        bob_p.shut_down()
+    assert co_sent.keys() == un_sent.keys() and len(co_sent) == 4 * sessions
+    for i in check:
+        for step in ("step_1", "step_4b", "step_4i", "step_5"):
+            k = f"{step}_session_{i + 1}"
+            assert co_sent[k] == un_sent[k], k
+        assert co_res[i] == un_res[i]
+    dec = engine.download(bob_p.decrypt_raw_batch(engine.upload(co_res, 2 * bob_p.mod_n.nwords)))
+    assert dec == [int(x <= y) for x, y in pairs]
+    for side in ("alice", "bob"):
+        assert stats[side]["largest"] == sessions and stats[side]["fallbacks"] == 0
+    assert stats["alice"]["calls"] == 3 and stats["bob"]["calls"] == 3      # step 1 / 4 / 6+7; the randomizers ahead of time / steps 2-4b / 4j+5
