@@ -16,6 +16,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import random
 import subprocess
 import sys
 import tempfile
@@ -381,6 +382,80 @@ def latency_single_leg(torch, eng, keys):
                     "exchange with one launch per ciphertext operator (Initiator.fuse_steps = False), identical ciphertexts; static_step_chain_ms: "
                     "steps 1-7 without randomization as a batch of one.  A single comparison is a chain of dependent launches on an otherwise idle "
                     "chip: the product has no CPU path, cpu_oracle_ms (same box, one core) is the reference point"}
+
+
+def concurrent_sessions_leg(torch, eng, keys, sessions: int = 1024, shapes=(("paillier_1024", "dgk_1024_l16", 16), ("paillier_2048", "dgk_2048_l32", 32)),
+                            cpu_run=None, window: int = 16):
+    """The reference's primary usage at scale (SC/initiator.py:69-175, :86-87; test/unit/test_secure_comparison.py:804-835): `sessions`
+    concurrent perform_secure_comparison(x_i, y_i) calls on ONE Initiator / KeyHolder pair over the in-memory transport, every one a
+    full interactive comparison with its own draws and 4 + 2(l+1) randomizers.  The players' session coalescer (coalesce.py) runs the
+    sessions' steps as batch launches; `uncoalesced` is the same call shape with one library call per session and step (round 4's
+    path: N sessions cost N single-comparison chains).  Wall clock of the whole asyncio run, Python included."""
+    import asyncio
+
+    from protocols.secure_comparison_amd import DGK, Initiator, KeyHolder, Paillier
+    from protocols.secure_comparison_amd.communicator import InMemoryCommunicator
+
+    out = []
+    for pname, dname, l in shapes:
+        pj, dj = keys[pname], keys[dname]
+        p, q = int(pj["p"], 16), int(pj["q"], 16)
+        H = lambda name: int(dj[name], 16)  # noqa: E731
+        bob_p = Paillier(p * q, p, q, engine=eng)
+        bob_d = DGK(H("p") * H("q"), H("g"), H("h"), H("u"), dj["t"], H("p"), H("q"), H("v_p"), H("v_q"), engine=eng, randomizer_bits=400,
+                    fixed_base_window=window)
+        alice_d = bob_d.public_copy()
+        alice_d.prepare(), bob_d.prepare()                 # tables: untimed set-up, like key generation
+        rng = random.Random(l)
+        pairs = [(rng.randrange(1 << l), rng.randrange(1 << l)) for _ in range(sessions)]
+        for i in range(0, sessions, 8):
+            pairs[i] = (pairs[i][0], pairs[i][0])           # equal inputs in every eighth session (SURVEY 8(d))
+
+        def run(n: int, coalesce: bool):
+            comm = InMemoryCommunicator()
+            alice, bob = Initiator(l, comm, "keyholder", bob_p.public_copy(), alice_d), KeyHolder(l, comm.peer(), "initiator", bob_p, bob_d)
+            alice.coalesce_sessions = bob.coalesce_sessions = coalesce
+
+            async def go():
+                a = [asyncio.ensure_future(alice.perform_secure_comparison(x, y)) for x, y in pairs[:n]]
+                b = [asyncio.ensure_future(bob.perform_secure_comparison()) for _ in range(n)]
+                res = await asyncio.gather(*a)
+                await asyncio.gather(*b)
+                return res
+
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = asyncio.run(go())
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            dec = eng.download(bob_p.decrypt_raw_batch(eng.upload([r.peek_value() for r in res], 2 * bob_p.mod_n.nwords)))
+            return dt, dec == [int(x <= y) for x, y in pairs[:n]], (alice._coalescer().stats, bob._coalescer().stats)
+
+        run(min(64, sessions), True)                       # programs, key objects, allocator, the background context
+        runs = [run(sessions, True) for _ in range(3)]
+        dt = sorted(r[0] for r in runs)[1]
+        n_un = min(32, sessions)
+        run(4, False)
+        dt_un, ok_un, _ = run(n_un, False)
+        row = {"workload": "%d concurrent perform_secure_comparison sessions, l=%d, %s + %s" % (sessions, l, pname, dname),
+               "value": sessions / dt, "unit": "comparisons/s", "seconds": dt, "sessions": sessions,
+               "batched_calls": {"initiator": runs[-1][2][0]["calls"], "keyholder": runs[-1][2][1]["calls"], "largest_batch": runs[-1][2][0]["largest"]},
+               "seconds_in_batched_calls": {"initiator": {k: round(v, 4) for k, v in runs[-1][2][0]["seconds"].items()},
+                                            "keyholder": {k: round(v, 4) for k, v in runs[-1][2][1]["seconds"].items()}},
+               "uncoalesced": {"value": n_un / dt_un, "sessions": n_un}, "correct": all(r[1] for r in runs) and ok_un}
+        if cpu_run is not None:
+            try:
+                cb = cpu_run(pname, dname)
+                row["cpu_oracle"] = {"value": cb["value"], "cores": cb["cores"], "arith": cb["arith"], "sample": cb["count"]}
+                row["ratio_to_cpu_oracle"] = row["value"] / cb["value"]
+            except Exception as exc:  # pragma: no cover
+                row["cpu_oracle"] = {"error": str(exc)[:200]}
+        bob_p.shut_down()
+        out.append(row)
+    return {"shapes": out,
+            "note": "wall clock of asyncio.run over all sessions of both players in one process and event loop (Python object handling included), median of 3; "
+                    "every session draws its own randomness and sends / receives its own four messages; cpu_oracle = oracle.compare on the box's host cores "
+                    "(same key sizes and l, multiprocessing); informational, never `value`"}
 
 
 def workload_name(B, l, pbits, dbits):
@@ -812,10 +887,12 @@ def measure(args, torch, dist, rank: int, world: int, full: bool, rt=None):
             "roofline_hbm": {"bound": "hbm", "achieved": abytes * value / world / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": abytes * value / world / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_comparison": abytes},
         }
+        cpu_run, py_cpu, cores_cpu = None, None, 0
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N = 1 only
             cores = min(os.cpu_count() or 1, 16)
             sample = min(B, args.cpu_sample or 64 * cores)
             py = "/opt/conda/bin/python3.9" if os.path.exists("/opt/conda/bin/python3.9") else sys.executable
+            py_cpu, cores_cpu = py, cores
             try:
                 stride = max(1, B // sample)
                 idx = [i * stride for i in range(sample)]
@@ -934,9 +1011,17 @@ def measure(args, torch, dist, rank: int, world: int, full: bool, rt=None):
                 return {"value": B / pcie_s, "unit": "comparisons/s", "host_bytes_per_comparison":
                                          sum(t.numel() * t.element_size() for t in host_in) / B + r2.shape[-1] * 4}
 
+            def leg_concurrent_sessions():
+                # ---- many concurrent SINGLE comparisons on one player pair (the reference's call shape), coalesced into batch launches
+                def cpu_shape(pname, dgk_name):
+                    return cpu_run(py_cpu, 4 * cores_cpu, cores_cpu, pname, dgk_name, None) if cpu_run is not None else None
+
+                return concurrent_sessions_leg(torch, eng, keys, cpu_run=cpu_shape if cpu_run is not None else None)
+
             guarded("window_sensitivity", leg_window_sensitivity)
             guarded("interactive_protocol", leg_interactive_protocol)
             guarded("latency_single", leg_latency_single)
+            guarded("concurrent_sessions", leg_concurrent_sessions)
             guarded("online_phase_only", leg_online_phase_only)
             guarded("pcie_inclusive", leg_pcie_inclusive)
         if not args.no_other_configs and world == 1 and (B, l, args.pbits) == (65536, 32, 2048):

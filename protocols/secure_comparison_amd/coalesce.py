@@ -16,7 +16,11 @@ with the same draws (tests/test_gpu_round5.py, tests/test_coalesce_cpu.py).
 from __future__ import annotations
 
 import asyncio
+import gc
+import time
 from typing import Any, Callable, Sequence
+
+import numpy as np
 
 
 class _Queue:
@@ -43,7 +47,7 @@ class StepCoalescer:
         self.max_batch = max(1, int(max_batch))
         self.linger_s = float(linger_s)
         self._queues: dict[str, _Queue] = {}
-        self.stats = {"calls": 0, "items": 0, "largest": 0, "fallbacks": 0}
+        self.stats = {"calls": 0, "items": 0, "largest": 0, "fallbacks": 0, "seconds": {}}     # seconds: wall clock inside the batched calls, per step
 
     async def submit(self, kind: str, run: Callable[[list], Sequence], item: Any) -> Any:
         """Queue `item` for the step `kind`; `run(items)` makes ONE batched call for a list of such items and returns one result per
@@ -86,6 +90,11 @@ class StepCoalescer:
         self.stats["calls"] += 1
         self.stats["items"] += len(items)
         self.stats["largest"] = max(self.stats["largest"], len(items))
+        t0 = time.perf_counter()
+        # the batched call hands back tens of thousands of small objects (one ciphertext per row): with the cyclic collector running,
+        # every few hundred allocations trigger a pass over them (measured: 0.18 s instead of 0.03 s for 1024 sessions at l = 32)
+        gc_was_on = gc.isenabled()
+        gc.disable()
         try:
             results = list(run(items))
             if len(results) != len(items):
@@ -104,6 +113,10 @@ class StepCoalescer:
                         outcomes.append((True, list(run([it]))[0]))
                     except Exception as one:  # noqa: BLE001
                         outcomes.append((False, one))
+        finally:
+            if gc_was_on:
+                gc.enable()
+        self.stats["seconds"][kind] = self.stats["seconds"].get(kind, 0.0) + time.perf_counter() - t0
         for fut, (ok, value) in zip(futures, outcomes):
             if fut.done():                          # the session was cancelled while it waited
                 continue
@@ -111,3 +124,28 @@ class StepCoalescer:
                 fut.set_result(value)
             else:
                 fut.set_exception(value)
+
+
+# ---- word rows: how coalesced sessions hand ciphertext values on without ever making Python integers of them ------------------------
+def rows_of(cts: Sequence, nwords: int) -> np.ndarray:
+    """The values of a list of ciphertexts as an array [len][nwords] of little-endian 32-bit words: the very rows a coalesced peer's
+    batch launch produced when the ciphertexts still refer to consecutive rows of one array (no conversion, no copy), else converted
+    from their integers."""
+    block = cts[0]._block if cts else None
+    if block is not None and block.shape[-1] == nwords:
+        at = cts[0]._row
+        for c in cts:
+            if c._block is not block or c._row != at:
+                break
+            at += 1
+        else:
+            return block[cts[0]._row:at]
+    out = np.empty((len(cts), nwords), dtype="<u4")
+    for i, c in enumerate(cts):
+        out[i] = np.frombuffer(c.peek_value().to_bytes(4 * nwords, "little"), dtype="<u4")
+    return out
+
+
+def int_rows(values: Sequence[int], nwords: int) -> np.ndarray:
+    """Python integers as rows of words."""
+    return np.frombuffer(b"".join(v.to_bytes(4 * nwords, "little") for v in values), dtype="<u4").reshape(len(values), nwords)

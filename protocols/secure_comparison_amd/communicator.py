@@ -40,6 +40,12 @@ class InMemoryCommunicator:
         # of bytes.  False makes the batch protocol serialize as it would for a real transport (one pinned host buffer).
         self.device_tensors = device_tensors
 
+    def _watch(self, loop, fut) -> None:
+        if self.__dict__.get("_watch_loop") is not loop:
+            self._watched, self._watch_loop = [], loop
+            loop.call_later(min(1.0, max(0.01, self.timeout_s)), _check_deadlines, self, loop)
+        self._watched.append(fut)
+
     def peer(self) -> "InMemoryCommunicator":
         """A second endpoint on the same mailbox (hand it to the other player)."""
         return InMemoryCommunicator(self.mailbox, self.max_polls, self.device_tensors, self.timeout_s)
@@ -64,15 +70,19 @@ class InMemoryCommunicator:
     async def recv(self, party_id: str, msg_id: str) -> Any:
         if msg_id in self.mailbox:
             return self.mailbox.pop(msg_id)
-        fut = asyncio.get_running_loop().create_future()
+        loop = asyncio.get_running_loop()
+        fut = loop.create_future()
         waiters = self.mailbox.setdefault(_WAITERS, {})
         if msg_id in waiters:
             raise RuntimeError(f"two receivers wait for message {msg_id!r}")
         waiters[msg_id] = fut
+        if self.timeout_s is not None:
+            # one watchdog per endpoint and event loop instead of a timer per receive (a thousand sessions wait at once)
+            fut._sc_deadline = loop.time() + self.timeout_s        # type: ignore[attr-defined]
+            fut._sc_what = (msg_id, party_id)                      # type: ignore[attr-defined]
+            self._watch(loop, fut)
         try:
-            return await (fut if self.timeout_s is None else asyncio.wait_for(fut, self.timeout_s))
-        except asyncio.TimeoutError:
-            raise TimeoutError(f"no message {msg_id!r} from {party_id!r}") from None
+            return await fut
         finally:
             left = self.mailbox.get(_WAITERS)
             if left is not None and left.get(msg_id) is fut:
@@ -81,13 +91,34 @@ class InMemoryCommunicator:
                     del self.mailbox[_WAITERS]
 
 
+def _check_deadlines(comm: "InMemoryCommunicator", loop) -> None:
+    now, alive = loop.time(), []
+    for fut in comm._watched:
+        if fut.done():
+            continue
+        if now >= fut._sc_deadline:
+            msg_id, party_id = fut._sc_what
+            fut.set_exception(TimeoutError(f"no message {msg_id!r} from {party_id!r}"))
+        else:
+            alive.append(fut)
+    comm._watched = alive
+    if alive:
+        loop.call_later(min(1.0, max(0.01, min(f._sc_deadline for f in alive) - now)), _check_deadlines, comm, loop)
+    else:
+        comm._watch_loop = None
+
+
 def _as_on_wire(message: Any) -> Any:
     """Mimic what a serializing transport does to ciphertext objects (the reference's transports randomize a non-fresh
     ciphertext, with a warning, when it is serialized): nested tuples / lists are walked, other payloads pass through."""
-    if hasattr(message, "for_wire"):
-        return message.for_wire()
-    if isinstance(message, tuple):
-        return tuple(_as_on_wire(m) for m in message)
-    if isinstance(message, list):
+    fw = getattr(message, "for_wire", None)
+    if fw is not None:
+        return fw()
+    kind = type(message)
+    if kind is list:
+        if message and hasattr(type(message[0]), "wire_list"):
+            return type(message[0]).wire_list(message)           # a list of ciphertexts of one scheme: one pass, one look-up of the public scheme
         return [_as_on_wire(m) for m in message]
+    if kind is tuple:
+        return tuple(_as_on_wire(m) for m in message)
     return message

@@ -177,6 +177,17 @@ class Engine:
     def download(self, t: torch.Tensor) -> list[int]:
         return words_to_ints(t.detach().cpu().numpy().view(np.uint32))
 
+    def upload_words(self, arr: np.ndarray) -> torch.Tensor:
+        """A host array of little-endian 32-bit words ([...][nwords], uint32) as a device array of the same shape."""
+        arr = np.ascontiguousarray(arr, dtype="<u4")
+        if not arr.flags.writeable:                   # (np.frombuffer over bytes: torch refuses to wrap read-only memory quietly)
+            arr = arr.copy()
+        return torch.from_numpy(arr.view(np.int32)).to(self.device)
+
+    def download_words(self, t: torch.Tensor) -> np.ndarray:
+        """A device array as a host array of uint32 words (same shape)."""
+        return t.detach().cpu().numpy().view(np.uint32)
+
     def empty(self, count: int, nwords: int) -> torch.Tensor:
         return torch.empty((count, nwords), dtype=torch.int32, device=self.device)
 

@@ -153,81 +153,120 @@ class Initiator:
             co = self.__dict__["_step_coalescer"] = StepCoalescer(self.coalesce_max_batch, self.coalesce_linger_s)
         return co
 
+    def _draws(self):
+        """Where a coalesced session takes its random draws from (host_draws.py): `draw_source` when one was injected, else a buffered
+        stream of the engine's device generator (the OS generator where the engine has none)."""
+        src = self.__dict__.get("draw_source")
+        if src is None:
+            src = self.__dict__.get("_host_draws")
+            if src is None:
+                from .host_draws import HostDraws
+
+                src = self.__dict__["_host_draws"] = HostDraws.from_engine(self.scheme_paillier.engine)
+        return src
+
     async def _perform_coalesced(self, x: PaillierCiphertext | float, y: PaillierCiphertext | float, sid: int) -> PaillierCiphertext:
         """One session of SC/initiator.py:69-175 whose steps run inside the batch launches it shares with the other sessions in
         flight.  The session draws what the single path draws, where it draws it: the inputs of its 1 + (l + 1) randomizers
         (_start_randomness_generation, :205-210), r (:250), delta_A (:420), rho_i (:512), the shuffle (:223); the k-th
         `.randomize()` takes the randomizer the pool would have handed it (the pool is used from its end).  Plaintext inputs are
-        encrypted inside the step-1 launch (the unrandomized encryption 1 + mN of `unsafe_encrypt`, :93-102)."""
+        encrypted inside the step-1 launch (the unrandomized encryption 1 + mN of `unsafe_encrypt`, :93-102).  Ciphertext values
+        travel as rows of words (coalesce.rows_of): no Python integer is made of them on the way."""
+        import numpy as np
+
+        from .coalesce import rows_of
+
         pai, dgk, l = self.scheme_paillier, self.scheme_dgk, self.l_maximum_bit_length
         n, u = pai.public_key.n, dgk.public_key.u
-        co = self._coalescer()
-        rho_z = 1 + secrets.randbelow(n - 1)                                       # boot_randomness_generation(1): [[z]].randomize() (:109)
-        r_dgk = [secrets.randbits(dgk.randomizer_bits) for _ in range(l + 1)]      # boot_randomness_generation(l + 1) (:153-154)
-        # (ciphertext value, None) or (None, encoded plaintext): plaintext inputs are encrypted inside the batched call
-        xv = (x.get_value(), None) if isinstance(x, PaillierCiphertext) else (None, pai._encode(x))
-        yv = (y.get_value(), None) if isinstance(y, PaillierCiphertext) else (None, pai._encode(y))
+        co, src = self._coalescer(), self._draws()
+        rho_z = 1 + src.randbelow(n - 1)                                           # boot_randomness_generation(1): [[z]].randomize() (:109)
+        r_dgk = src.bits_rows(dgk.randomizer_bits, l + 1)                          # boot_randomness_generation(l + 1) (:153-154)
+        # (ciphertext, None) or (None, encoded plaintext): plaintext inputs are encrypted inside the batched call
+        xv = (x.consume(), None) if isinstance(x, PaillierCiphertext) else (None, pai._encode(x))
+        yv = (y.consume(), None) if isinstance(y, PaillierCiphertext) else (None, pai._encode(y))
         assert (1 << (l + 2)) < n // 2
-        r = secrets.randbelow(n)                                                   # step 1 (:250)
-        z = await co.submit("step_1", self._run_step_1, (xv, yv, r, rho_z))
-        await self.communicator.send(self.other_party, PaillierCiphertext(z, pai, fresh=True), msg_id=f"step_1_session_{sid}")
+        r = src.randbelow(n)                                                       # step 1 (:250)
+        z_enc, plain = await co.submit("step_1", self._run_step_1, (xv, yv, r, rho_z))
+        await self.communicator.send(self.other_party, z_enc, msg_id=f"step_1_session_{sid}")
         d_enc, beta_is_enc = await self.communicator.recv(self.other_party, msg_id=f"step_4b_session_{sid}")
         if len(beta_is_enc) != l:
             raise ValueError(f"received {len(beta_is_enc)} encrypted bits, expected {l}")
         assert 0 <= r < n                                                          # step 4c (:286-288)
-        _, delta_a = Initiator.step_4g()                                           # (:420)
-        rhos = [secrets.randbelow(u - 1) + 1 for _ in range(l + 1)]                 # step 4i (:512)
-        perm = Initiator.shuffle(list(range(l + 1)))                                # (:516): output k takes the blinded c at perm[k]
-        exps = [0] * (l + 1)
-        for k, src in enumerate(perm):
-            exps[src] = r_dgk[l - k]          # the k-th c.randomize() (:153-154) pops the pool's last entry: draw l - k, applied to the item that lands at output k
-        planes = [d_enc.get_value()] + [b.get_value() for b in beta_is_enc]
-        c = await co.submit("step_4", self._run_step_4, (planes, r, delta_a, rhos, perm, exps))
-        await self.communicator.send(self.other_party, [DGKCiphertext(v, dgk, fresh=True) for v in c], msg_id=f"step_4i_session_{sid}")
-        zeta_1_enc, zeta_2_enc, delta_b_enc = await self.communicator.recv(self.other_party, msg_id=f"step_5_session_{sid}")
-        res = await co.submit("step_6_7", self._run_step_6_7, (zeta_1_enc.get_value(), zeta_2_enc.get_value(), delta_b_enc.get_value(), r, delta_a))
-        return PaillierCiphertext(res, pai)
+        delta_a = src.coin()                                                       # step 4g (:420)
+        rhos = src.below_rows_nonzero(u, l + 1)                                    # step 4i (:512): rho_i = 1 + randbelow(u - 1)
+        perm = src.permutation(l + 1)                                              # (:516): output k takes the blinded c at perm[k]
+        exps = np.empty_like(r_dgk)
+        exps[perm] = r_dgk[::-1]              # the k-th c.randomize() (:153-154) pops the pool's last entry: draw l - k, applied to the item that lands at output k
+        planes = rows_of([d_enc.consume()] + [b.consume() for b in beta_is_enc], dgk.mod_n.nwords)
+        c_is_enc = await co.submit("step_4", self._run_step_4, (planes, plain, delta_a, rhos, perm, exps))
+        await self.communicator.send(self.other_party, c_is_enc, msg_id=f"step_4i_session_{sid}")
+        three = await self.communicator.recv(self.other_party, msg_id=f"step_5_session_{sid}")
+        if len(three) != 3:
+            raise ValueError(f"received {len(three)} ciphertexts, expected [[zeta_1]], [[zeta_2]], [[delta_B]]")
+        return await co.submit("step_6_7", self._run_step_6_7, (rows_of([t.consume() for t in three], 2 * pai.mod_n.nwords), plain, delta_a))
 
-    def _alice_plain(self, rs: list[int]) -> AlicePlain:
-        """Alice's plaintext-side values (SC/initiator.py:270, :289, :373, :559-562) for the blinding values `rs`: she knows r, so
-        they are host integers uploaded with the batch -- the sessions of a later step need not be those of an earlier one."""
-        pai, l = self.scheme_paillier, self.l_maximum_bit_length
-        e, n, nw = pai.engine, pai.public_key.n, pai.mod_n.nwords
-        mask, half = (1 << l) - 1, (n - 1) // 2
-        return AlicePlain(e.upload(rs, nw), e.upload_u64([r & mask for r in rs]), e.upload_u64([(r - n) & mask for r in rs]),
-                          e.upload_u64([int(r < half) for r in rs]), e.upload([r >> l for r in rs], nw))
+    def _run_step_1(self, items: list) -> list:
+        """Step 1 + `.randomize()` of K sessions: one sc_initiator_step1 call (the pair exponentiation rho_z^N fused in).  Per session:
+        ([[z]] as a fresh ciphertext, Alice's plaintext-side values of SC/initiator.py:270, :289, :373, :559-562 -- alpha, alpha~,
+        [r < (N-1)/2] and the row of r div 2^l -- for the session's later steps, whose batches need not be this one)."""
+        import numpy as np
 
-    def _run_step_1(self, items: list) -> list[int]:
-        """Step 1 + `.randomize()` of K sessions: one sc_initiator_step1 call (the pair exponentiation rho_z^N fused in)."""
+        from .coalesce import int_rows, rows_of
+
         pai, l = self.scheme_paillier, self.l_maximum_bit_length
-        e, nw = pai.engine, pai.mod_n.nwords
-        xy = e.upload([(it[c][0] or 0) for c in (0, 1) for it in items], 2 * nw)          # rows 0 .. K-1: [[x]], K .. 2K-1: [[y]]
-        plain = [(c * len(items) + b, it[c][1]) for c in (0, 1) for b, it in enumerate(items) if it[c][0] is None]
+        e, nw, k = pai.engine, pai.mod_n.nwords, len(items)
+        xy = np.zeros((2 * k, 2 * nw), dtype="<u4")                                 # rows 0 .. K-1: [[x]], K .. 2K-1: [[y]]
+        plain = []
+        for c in (0, 1):
+            for b, it in enumerate(items):
+                ct, m = it[c]
+                if ct is None:
+                    plain.append((c * k + b, m))
+                else:
+                    xy[c * k + b] = rows_of([ct], 2 * nw)[0]
+        t = e.upload_words(xy)
         if plain:                                     # unsafe_encrypt of the plaintext inputs (SC/initiator.py:93-102), one launch
-            rows = torch.tensor([i for i, _ in plain], dtype=torch.int64, device=xy.device)
-            xy[rows] = pai.encrypt_raw_batch(e.upload([m for _, m in plain], nw))
-        z, _ = Initiator.step_1_batch(xy[:len(items)], xy[len(items):], l, pai, e.upload([it[2] for it in items], nw), e.upload([it[3] for it in items], nw))
-        return e.download(z)
+            rows = torch.tensor([i for i, _ in plain], dtype=torch.int64, device=t.device)
+            t[rows] = pai.encrypt_raw_batch(e.upload_words(int_rows([m for _, m in plain], nw)))
+        z, p = Initiator.step_1_batch(t[:k], t[k:], l, pai, e.upload_words(int_rows([it[2] for it in items], nw)),
+                                      e.upload_words(int_rows([it[3] for it in items], nw)))
+        zs, shift = e.download_words(z), e.download_words(p.r_shift)
+        alpha, tilde, small = p.alpha.tolist(), p.alpha_tilde.tolist(), p.r_small.tolist()
+        zc = PaillierCiphertext.rows(zs, pai.for_wire(), fresh=True)
+        return [(zc[b], (alpha[b], tilde[b], small[b], shift[b])) for b in range(k)]
 
-    def _run_step_4(self, items: list) -> list[list[int]]:
-        """Steps 4c .. 4i + the l + 1 `.randomize()` of K sessions: one sc_initiator_step4 call on bit-major planes [l+1][K]."""
+    def _run_step_4(self, items: list) -> list:
+        """Steps 4c .. 4i + the l + 1 `.randomize()` of K sessions: one sc_initiator_step4 call on bit-major planes [l+1][K]; per session
+        the l + 1 fresh ciphertexts [c_i] as sent."""
+        import numpy as np
+
         dgk, l = self.scheme_dgk, self.l_maximum_bit_length
         e, nd, k = dgk.engine, dgk.mod_n.nwords, len(items)
         ew, er = (dgk.public_key.u.bit_length() + 31) // 32, (dgk.randomizer_bits + 31) // 32
-        major = lambda col, w: e.upload([it[col][j] for j in range(l + 1) for it in items], w).reshape(l + 1, k, w)   # noqa: E731
-        planes = major(0, nd)
-        c, _ = Initiator.step_4_batch(planes[0], planes[1:], self._alice_plain([it[1] for it in items]), e.upload_u64([it[2] for it in items]), dgk,
-                                      major(3, ew), e.upload_u64([v for it in items for v in it[4]]).reshape(k, l + 1), major(5, er))
-        flat = e.download(c.reshape((l + 1) * k, nd))
-        return [[flat[j * k + b] for j in range(l + 1)] for b in range(k)]
+        planes, rhos, exps = (np.empty((l + 1, k, w), dtype="<u4") for w in (nd, ew, er))
+        for b, it in enumerate(items):
+            planes[:, b], rhos[:, b], exps[:, b] = it[0], it[3], it[5]
+        flags = lambda col: e.upload_u64([it[1][col] & 0xFFFFFFFFFFFFFFFF for it in items])   # noqa: E731
+        plain = AlicePlain(None, flags(0), flags(1), flags(2), None)
+        tp = e.upload_words(planes)
+        c, _ = Initiator.step_4_batch(tp[0], tp[1:], plain, e.upload_u64([it[2] for it in items]), dgk, e.upload_words(rhos),
+                                      torch.from_numpy(np.array([it[4] for it in items], dtype=np.int64)).to(tp.device), e.upload_words(exps))
+        cv, pub = e.download_words(c), dgk.for_wire()
+        return [DGKCiphertext.rows(cv[:, b], pub, fresh=True) for b in range(k)]
 
-    def _run_step_6_7(self, items: list) -> list[int]:
-        """Steps 6 and 7 of K sessions: one sc_initiator_step67 call."""
+    def _run_step_6_7(self, items: list) -> list:
+        """Steps 6 and 7 of K sessions: one sc_initiator_step67 call; per session [[x <= y]]."""
+        import numpy as np
+
         pai, l = self.scheme_paillier, self.l_maximum_bit_length
-        e, nw = pai.engine, pai.mod_n.nwords
-        up = lambda col: e.upload([it[col] for it in items], 2 * nw)   # noqa: E731
-        res = Initiator.step_6_7_batch(e.upload_u64([it[4] for it in items]), up(2), up(0), up(1), self._alice_plain([it[3] for it in items]), l, pai)
-        return e.download(res)
+        e, nw, k = pai.engine, pai.mod_n.nwords, len(items)
+        three, shift = np.empty((3, k, 2 * nw), dtype="<u4"), np.empty((k, nw), dtype="<u4")
+        for b, it in enumerate(items):
+            three[:, b], shift[b] = it[0], it[1][3]
+        t = e.upload_words(three)
+        plain = AlicePlain(None, None, None, e.upload_u64([it[1][2] & 0xFFFFFFFFFFFFFFFF for it in items]), e.upload_words(shift))
+        res = e.download_words(Initiator.step_6_7_batch(e.upload_u64([it[2] for it in items]), t[2], t[0], t[1], plain, l, pai))
+        return PaillierCiphertext.rows(res, pai)
 
     async def perform_secure_comparison_batch(self, x_enc: torch.Tensor, y_enc: torch.Tensor, draws=None,
                                               source: str = "device", engine=None, generator=None, chunks: int = 1) -> torch.Tensor:

@@ -121,30 +121,41 @@ class KeyHolder:
             co = self.__dict__["_step_coalescer"] = StepCoalescer(self.coalesce_max_batch, self.coalesce_linger_s)
         return co
 
+    def _draws(self):
+        """See Initiator._draws."""
+        src = self.__dict__.get("draw_source")
+        if src is None:
+            src = self.__dict__.get("_host_draws")
+            if src is None:
+                from .host_draws import HostDraws
+
+                src = self.__dict__["_host_draws"] = HostDraws.from_engine(self.scheme_paillier.engine)
+        return src
+
     async def _perform_coalesced(self, sid: int) -> None:
         """One session of SC/keyholder.py:70-133 whose steps run inside the batch launches it shares with the other sessions in
         flight (Initiator._perform_coalesced).  The session draws the inputs of its 3 + (l + 1) randomizers where
         _start_randomness_generation draws them (:174-179); the k-th `.randomize()` takes what the pool would have handed it."""
-        import secrets
+        from .coalesce import rows_of
 
         pai, dgk, l = self.scheme_paillier, self.scheme_dgk, self.l_maximum_bit_length
         n = pai.public_key.n
-        co = self._coalescer()
-        rho = [1 + secrets.randbelow(n - 1) for _ in range(3)]                       # boot_randomness_generation(3) (:126-128)
-        r_dgk = [secrets.randbits(dgk.randomizer_bits) for _ in range(l + 1)]        # boot_randomness_generation(l + 1) (:106-108)
+        co, src = self._coalescer(), self._draws()
+        rho = [1 + src.randbelow(n - 1) for _ in range(3)]                          # boot_randomness_generation(3) (:126-128)
+        r_dgk = src.bits_rows(dgk.randomizer_bits, l + 1)                           # boot_randomness_generation(l + 1) (:106-108)
         rho3 = rho[::-1]                        # the pool is used from its end: [[zeta_1]], [[zeta_2]], [[delta_B]] take draws 2, 1, 0
         ahead = None
         if self.background_randomness:          # the three Paillier randomizers are not needed before step 5: queued on the second context now
             ahead = await co.submit("randomizers_step_5", self._run_randomizers_ahead, rho3)
         z_enc = await self.communicator.recv(self.other_party, msg_id=f"step_1_session_{sid}")
-        d, beta, zeta_1, zeta_2 = await co.submit("step_2_4b", self._run_step_2_4b, (z_enc.peek_value(), r_dgk[::-1]))   # [d] first, then [beta_i]
-        await self.communicator.send(self.other_party, (DGKCiphertext(d, dgk, fresh=True), [DGKCiphertext(v, dgk, fresh=True) for v in beta]),
-                                     msg_id=f"step_4b_session_{sid}")
+        z_row = rows_of([z_enc], 2 * pai.mod_n.nwords)[0]
+        d_enc, beta_is_enc, zetas = await co.submit("step_2_4b", self._run_step_2_4b, (z_row, r_dgk[::-1]))   # [d] first, then [beta_i]
+        await self.communicator.send(self.other_party, (d_enc, beta_is_enc), msg_id=f"step_4b_session_{sid}")
         c_is_enc = await self.communicator.recv(self.other_party, msg_id=f"step_4i_session_{sid}")
         if len(c_is_enc) != l + 1:
             raise ValueError(f"received {len(c_is_enc)} blinded values, expected {l + 1}")
-        three = await co.submit("step_4j_5", self._run_step_4j_5, ([ct.peek_value() for ct in c_is_enc], zeta_1, zeta_2, rho3, ahead))
-        await self.communicator.send(self.other_party, tuple(PaillierCiphertext(v, pai, fresh=True) for v in three), msg_id=f"step_5_session_{sid}")
+        three = await co.submit("step_4j_5", self._run_step_4j_5, (rows_of(c_is_enc, dgk.mod_n.nwords), zetas, rho3, ahead))
+        await self.communicator.send(self.other_party, three, msg_id=f"step_5_session_{sid}")
 
     def _run_randomizers_ahead(self, items: list) -> list:
         """rho^N mod N^2 for the 3 K randomizer bases of K sessions, QUEUED on the scheme's background context (the reference starts
@@ -153,45 +164,57 @@ class KeyHolder:
         job = self.scheme_paillier._launch_randomness_values([v for it in items for v in it])
         if job is None:
             return [None] * len(items)
-        shared = {"job": job, "values": None}
+        shared = {"job": job, "rows": None}
         return [(shared, 3 * i) for i in range(len(items))]
 
     def _run_step_2_4b(self, items: list) -> list:
-        """Steps 2, 4a, 4b + the l + 1 `.randomize()` of K sessions: one sc_keyholder_step2_4b call; per session ([d], [beta_i],
-        zeta_1, zeta_2) -- the two plaintext quotients travel back to step 5 with the session."""
+        """Steps 2, 4a, 4b + the l + 1 `.randomize()` of K sessions: one sc_keyholder_step2_4b call; per session ([d], [[beta_i]] as
+        fresh ciphertexts, and the rows of the two plaintext quotients zeta_1, zeta_2, which travel to step 5 with the session)."""
+        import numpy as np
+
         pai, dgk, l = self.scheme_paillier, self.scheme_dgk, self.l_maximum_bit_length
-        e, nw, nd, k = pai.engine, pai.mod_n.nwords, dgk.mod_n.nwords, len(items)
+        e, nw, k = pai.engine, pai.mod_n.nwords, len(items)
         er = (dgk.randomizer_bits + 31) // 32
-        exps = e.upload([it[1][j] for j in range(l + 1) for it in items], er).reshape(l + 1, k, er)
-        plain, d, beta = KeyHolder.step_2_4b_batch(e.upload([it[0] for it in items], 2 * nw), l, pai, dgk, exps)
-        dv, bv = e.download(d), e.download(beta.reshape(l * k, nd))
-        z1, z2 = e.download(plain.zeta_1), e.download(plain.zeta_2)
-        return [(dv[b], [bv[i * k + b] for i in range(l)], z1[b], z2[b]) for b in range(k)]
+        z, exps = np.empty((k, 2 * nw), dtype="<u4"), np.empty((l + 1, k, er), dtype="<u4")
+        for b, it in enumerate(items):
+            z[b], exps[:, b] = it[0], it[1]
+        plain, d, beta = KeyHolder.step_2_4b_batch(e.upload_words(z), l, pai, dgk, e.upload_words(exps))
+        dv, bv = e.download_words(d), e.download_words(beta)
+        z1, z2 = e.download_words(plain.zeta_1), e.download_words(plain.zeta_2)
+        pub = dgk.for_wire()
+        ds = DGKCiphertext.rows(dv, pub, fresh=True)
+        return [(ds[b], DGKCiphertext.rows(bv[:, b], pub, fresh=True), (z1[b], z2[b])) for b in range(k)]
 
     def _run_step_4j_5(self, items: list) -> list:
         """Steps 4j, 5 + the three `.randomize()` of K sessions: one sc_keyholder_step4j_5 call (the randomizers finished ahead of
-        time where every session of the batch has them, else computed in the call)."""
+        time where every session of the batch has them, else computed in the call); per session the three fresh ciphertexts."""
+        import numpy as np
+
+        from .coalesce import int_rows
+
         pai, dgk, l = self.scheme_paillier, self.scheme_dgk, self.l_maximum_bit_length
         e, nw, nd, k = pai.engine, pai.mod_n.nwords, dgk.mod_n.nwords, len(items)
-        c = e.upload([it[0][j] for j in range(l + 1) for it in items], nd).reshape(l + 1, k, nd)
-        z = e.upload([it[1] for it in items] + [it[2] for it in items], nw)
-        plain = BobPlain(None, None, None, z[:k], z[k:])
-        ready = all(it[4] is not None for it in items)
+        c, zeta = np.empty((l + 1, k, nd), dtype="<u4"), np.empty((2, k, nw), dtype="<u4")
+        for b, it in enumerate(items):
+            c[:, b], zeta[0, b], zeta[1, b] = it[0], it[1][0], it[1][1]
+        tz = e.upload_words(zeta)
+        ready = all(it[3] is not None for it in items)
         if ready:
-            rows = []
-            for it in items:
-                shared, at = it[4]
-                if shared["values"] is None:             # first session of that background batch to get here: wait for it, read it once
+            rho = np.empty((3, k, 2 * nw), dtype="<u4")
+            for b, it in enumerate(items):
+                shared, at = it[3]
+                if shared["rows"] is None:                # first session of that background batch to get here: wait for it, read it once
                     t, ev, twin = shared["job"]
                     ev.synchronize()
-                    shared["values"] = twin.engine.download(t)
-                rows.append(shared["values"][at:at + 3])
-            rho3 = e.upload([rows[b][j] for j in range(3) for b in range(k)], 2 * nw)
+                    shared["rows"] = twin.engine.download_words(t)
+                rho[:, b] = shared["rows"][at:at + 3]
+            rho3 = e.upload_words(rho).reshape(3 * k, 2 * nw)
         else:
-            rho3 = e.upload([it[3][j] for j in range(3) for it in items], nw)
-        _, z1, z2, db = KeyHolder.step_4j_5_batch(c, plain, pai, dgk, rho3, randomizers_ready=ready)
-        a, b_, c_ = e.download(z1), e.download(z2), e.download(db)
-        return list(zip(a, b_, c_))
+            rho3 = e.upload_words(int_rows([it[2][j] for j in range(3) for it in items], nw))
+        _, z1, z2, db = KeyHolder.step_4j_5_batch(e.upload_words(c), BobPlain(None, None, None, tz[0], tz[1]), pai, dgk, rho3, randomizers_ready=ready)
+        out3 = np.stack([e.download_words(z1), e.download_words(z2), e.download_words(db)])       # [3][K][2nw]
+        pub = pai.for_wire()
+        return [tuple(PaillierCiphertext.rows(out3[:, b], pub, fresh=True)) for b in range(k)]
 
     async def perform_secure_comparison_batch(self, draws=None, source: str = "device", generator=None) -> None:
         """Bob's side of Initiator.perform_secure_comparison_batch.  `draws` (batch.BatchDraws; Bob's fields) injects

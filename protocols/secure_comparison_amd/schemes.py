@@ -89,27 +89,64 @@ class _PublicKey:
 # ciphertext objects (single-ciphertext API of the reference)
 # =====================================================================================================
 class _Ciphertext:
-    def __init__(self, raw_value: int, scheme: Any, *, fresh: bool = False) -> None:
-        self._raw_value = int(raw_value)
+    """A ciphertext: an integer modulo the scheme's ciphertext modulus, bound to its scheme.  The integer may be held as a ROW OF
+    WORDS instead (`raw_value` = (array [rows][nwords] of uint32, row index)): what the batch launches of coalesced sessions hand
+    out -- the Python integer is only made when somebody asks for it (`value`, `peek_value`, `get_value`)."""
+
+    __slots__ = ("_raw_value", "_block", "_row", "scheme", "_fresh")      # (no per-object dict: a message holds l + 1 of these, a
+                                                                         # thousand concurrent sessions a hundred thousand)
+
+    def __init__(self, raw_value: Any, scheme: Any, *, fresh: bool = False) -> None:
+        if isinstance(raw_value, tuple):
+            self._raw_value, (self._block, self._row) = None, raw_value
+        else:
+            self._raw_value, self._block, self._row = int(raw_value), None, 0
         self.scheme = scheme
         self._fresh = fresh
+
+    @classmethod
+    def rows(cls, block, scheme: Any, fresh: bool = False) -> list:
+        """One ciphertext per row of `block` ([rows][nwords] words), in order -- what a batch launch hands to a session."""
+        out = []
+        for j in range(len(block)):
+            c = object.__new__(cls)
+            c._raw_value, c._block, c._row, c.scheme, c._fresh = None, block, j, scheme, fresh
+            out.append(c)
+        return out
+
+    def _int(self) -> int:
+        v = self._raw_value
+        if v is None:
+            v = self._raw_value = int.from_bytes(self._block[self._row].tobytes(), "little")
+        return v
 
     @property
     def value(self) -> int:
         """The ciphertext integer; reading it this way ends the ciphertext's freshness (it may have been observed)."""
         self._fresh = False
-        return self._raw_value
+        return self._int()
 
     def peek_value(self) -> int:
         """The ciphertext integer without touching the freshness flag."""
-        return self._raw_value
+        return self._int()
+
+    def peek_words(self):
+        """(array, row) when the value is held as a row of little-endian 32-bit words, else None."""
+        return None if self._block is None else (self._block, self._row)
 
     def get_value(self) -> int:
         """Value for use in a homomorphic operation: warns when a fresh ciphertext is consumed that way."""
         if self._fresh:
             warnings.warn(WARN_INEFFICIENT_HOM_OPERATION, UserWarning)
         self._fresh = False
-        return self._raw_value
+        return self._int()
+
+    def consume(self) -> "_Ciphertext":
+        """get_value's bookkeeping without making the integer (coalesced sessions pass word rows on)."""
+        if self._fresh:
+            warnings.warn(WARN_INEFFICIENT_HOM_OPERATION, UserWarning)
+        self._fresh = False
+        return self
 
     def for_wire(self):
         """What a transport should put on the wire: a fresh ciphertext (randomizing first, with a warning, if this one is
@@ -118,7 +155,30 @@ class _Ciphertext:
             warnings.warn(WARN_UNFRESH_SERIALIZATION, UserWarning)
             self.randomize()
         self._fresh = False
-        return type(self)(self._raw_value, self.scheme.for_wire())     # what arrives is bound to the PUBLIC scheme
+        out = object.__new__(type(self))             # what arrives is bound to the PUBLIC scheme
+        out._raw_value, out._block, out._row, out.scheme, out._fresh = self._raw_value, self._block, self._row, self.scheme.for_wire(), False
+        return out
+
+    @classmethod
+    def wire_list(cls, cts: list) -> list:
+        """for_wire() for a list of ciphertexts (a message of l + 1 of them): the same flags and bindings as calling it on each.  A fresh
+        ciphertext that is bound to a public scheme already is handed over as it is (an in-memory transport moves objects; the sender
+        of a message does not keep using them), everything else is copied onto the public scheme."""
+        out, scheme, pub = [], None, None
+        for c in cts:
+            if type(c) is not cls or not c._fresh:
+                out.append(c.for_wire())
+                continue
+            if c.scheme is not scheme:
+                scheme, pub = c.scheme, c.scheme.for_wire()
+            c._fresh = False
+            if pub is scheme:
+                out.append(c)
+                continue
+            w = object.__new__(cls)
+            w._raw_value, w._block, w._row, w.scheme, w._fresh = c._raw_value, c._block, c._row, pub, False
+            out.append(w)
+        return out
 
     @property
     def fresh(self) -> bool:
@@ -128,12 +188,12 @@ class _Ciphertext:
         """In-place re-randomization (SC/initiator.py:109,153-154; SC/keyholder.py:106-108,126-128)."""
         if self._fresh:
             warnings.warn(WARN_INEFFICIENT_RANDOMIZATION, UserWarning)
-        self._raw_value = self.scheme._apply_randomness(self._raw_value, self.scheme.get_randomness())
+        self._raw_value, self._block = self.scheme._apply_randomness(self._int(), self.scheme.get_randomness()), None
         self._fresh = True
         return self
 
     def copy(self):
-        return type(self)(self._raw_value, self.scheme)
+        return type(self)(self._int(), self.scheme)
 
     # ---- operator algebra
     def _coerce(self, other: Any):
@@ -173,21 +233,25 @@ class _Ciphertext:
         return self.__mul__(scalar)
 
     def __eq__(self, other: object) -> bool:
-        return isinstance(other, _Ciphertext) and self._raw_value == other._raw_value and self.scheme == other.scheme
+        return isinstance(other, _Ciphertext) and self._int() == other._int() and self.scheme == other.scheme
 
     def __hash__(self) -> int:
-        return hash((self._raw_value, id(self.scheme)))
+        return hash((self._int(), id(self.scheme)))
 
     def __repr__(self) -> str:
-        return f"<{type(self).__name__} {self._raw_value:#x}>"
+        return f"<{type(self).__name__} {self._int():#x}>"
 
 
 class PaillierCiphertext(_Ciphertext):
     """Paillier ciphertext: PaillierCiphertext(value, scheme) as in the reference's tests (:176)."""
 
+    __slots__ = ()
+
 
 class DGKCiphertext(_Ciphertext):
     """DGK ciphertext."""
+
+    __slots__ = ()
 
 
 # =====================================================================================================

@@ -14,7 +14,7 @@ from protocols.secure_comparison_amd import Initiator, KeyHolder
 _stream: contextvars.ContextVar = contextvars.ContextVar("session_stream")
 
 
-def run_sessions(pairs, l, bob_p, bob_d, coalesce: bool, alice_paillier=None, strict: bool = True, seed: int = 5):
+def run_sessions(pairs, l, bob_p, bob_d, coalesce: bool, alice_paillier=None, strict: bool = True, seed: int = 5, replay: bool = True):
     """(results as integers, {msg_id: [ciphertext integers]}, coalescer statistics of both players)."""
     sent = {}
 
@@ -31,6 +31,10 @@ def run_sessions(pairs, l, bob_p, bob_d, coalesce: bool, alice_paillier=None, st
     alice = Initiator(l, Tap(box), "bob", alice_paillier)
     bob = KeyHolder(l, Tap(box), "alice", bob_p, bob_d)
     alice.coalesce_sessions = bob.coalesce_sessions = coalesce
+    if replay:      # every draw through `secrets`, one call per value, in the order the single path makes them: the seeded streams replay
+        from protocols.secure_comparison_amd.host_draws import SecretsDraws
+
+        alice.draw_source = bob.draw_source = SecretsDraws()
 
     async def as_session(tag, i, coro_fn):
         _stream.set(random.Random(f"{seed}:{tag}:{i}"))

@@ -227,6 +227,12 @@ class OracleEngine:
     def download(self, t):
         return words_to_ints(t.detach().cpu().contiguous().numpy().view(np.uint32))
 
+    def upload_words(self, arr):
+        return torch.from_numpy(np.ascontiguousarray(arr, dtype="<u4").view(np.int32).copy())
+
+    def download_words(self, t):
+        return t.detach().cpu().contiguous().numpy().view(np.uint32)
+
     def empty(self, count, nwords):
         return torch.zeros((count, nwords), dtype=torch.int32)
 

@@ -72,7 +72,13 @@ def _run_single(engine, bob_p, bob_d, l, x, y, fused, seed):
     try:
         box = {}
         alice, bob = Initiator(l, Tap(box), "bob"), KeyHolder(l, Tap(box), "alice", bob_p, bob_d)
-        alice.fuse_steps = bob.fuse_steps = fused
+        # fused: True = the default path (steps as batch launches through the session coalescer; its draws replayed through `secrets`),
+        # "alone" = the same five step-level calls per session without the coalescer (round 4's path), False = one launch per operator
+        alice.fuse_steps = bob.fuse_steps = bool(fused)
+        alice.coalesce_sessions = bob.coalesce_sessions = fused is True
+        from protocols.secure_comparison_amd.host_draws import SecretsDraws
+
+        alice.draw_source = bob.draw_source = SecretsDraws()
 
         async def go():
             res, _ = await asyncio.gather(alice.perform_secure_comparison(x, y), bob.perform_secure_comparison())
@@ -97,11 +103,12 @@ def test_fused_single_comparison_equals_the_operator_path(engine, keys, pbits, d
     bob_d = DGK(dgk.n, dgk.g, dgk.h, dgk.u, dgk.t, dgk.p, dgk.q, dgk.v_p, dgk.v_q, engine=engine, randomizer_bits=400)
     for x, y in ((23, 42), (42, 23), (-7, -7)):
         fused, sent_f = _run_single(engine, bob_p, bob_d, l, x, y, True, 5)
+        alone, sent_a = _run_single(engine, bob_p, bob_d, l, x, y, "alone", 5)
         plain, sent_p = _run_single(engine, bob_p, bob_d, l, x, y, False, 5)
-        assert sent_f.keys() == sent_p.keys()
+        assert sent_f.keys() == sent_p.keys() == sent_a.keys()
         for k in sent_f:
-            assert sent_f[k] == sent_p[k], k
-        assert fused.peek_value() == plain.peek_value() and bob_p.decrypt(fused) == int(x <= y)
+            assert sent_f[k] == sent_p[k] == sent_a[k], k
+        assert fused.peek_value() == plain.peek_value() == alone.peek_value() and bob_p.decrypt(fused) == int(x <= y)
 
 
 def test_chunked_byte_transport_equals_the_single_session(engine, keys):

@@ -135,7 +135,13 @@ def _run_single(world, x, y, fused, seed):
     try:
         box = {}
         alice, bob = Initiator(L, Tap(box), "bob"), KeyHolder(L, Tap(box), "alice", bob_p, bob_d)
-        alice.fuse_steps = bob.fuse_steps = fused
+        # fused: True = the default path (steps as batch launches through the session coalescer; its draws replayed through `secrets`),
+        # "alone" = the same five step-level calls per session without the coalescer (round 4's path), False = one launch per operator
+        alice.fuse_steps = bob.fuse_steps = bool(fused)
+        alice.coalesce_sessions = bob.coalesce_sessions = fused is True
+        from protocols.secure_comparison_amd.host_draws import SecretsDraws
+
+        alice.draw_source = bob.draw_source = SecretsDraws()
 
         async def go():
             res, _ = await asyncio.gather(alice.perform_secure_comparison(x, y), bob.perform_secure_comparison())
@@ -154,9 +160,10 @@ def test_fused_single_comparison_equals_the_operator_path(world, x, y):
     the same ciphertexts, bit for bit, as the reference-shaped body that walks the ciphertext operator algebra step by step --
     with the same random stream: every message of the exchange is compared, not only the result."""
     fused, sent_f = _run_single(world, x, y, True, 99)
+    alone, sent_a = _run_single(world, x, y, "alone", 99)
     plain, sent_p = _run_single(world, x, y, False, 99)
-    assert sent_f.keys() == sent_p.keys() and all(sent_f[k] == sent_p[k] for k in sent_f if not k.startswith("schemes"))
-    assert fused == plain and world[3].decrypt(world[3]._ct_class(fused, world[3])) == int(x <= y)
+    assert sent_f.keys() == sent_p.keys() == sent_a.keys() and all(sent_f[k] == sent_p[k] == sent_a[k] for k in sent_f if not k.startswith("schemes"))
+    assert fused == plain == alone and world[3].decrypt(world[3]._ct_class(fused, world[3])) == int(x <= y)
     assert _run_single(world, x, y, True, 100)[0] != fused          # another stream, other ciphertexts
 
 
