@@ -60,6 +60,47 @@ def algorithmic_bytes_per_comparison(l: int, pbits: int, dbits: int, rbits: int)
     return 2 * (2 * (l + 1) * ct_d) + 9 * ct_p + rand
 
 
+def fixed_base_table_bytes(window: int, rbits: int, dgk_bits: int, t_bits: int, keyholder_crt: bool = True) -> int:
+    """Device bytes of the fixed-base tables one GPU holds for a DGK key at `window`: Alice's rows for h modulo n (ceil(rbits / w)
+    windows of 2^w rows) plus, for a key holder that randomizes through CRT, the half-size rows for h modulo p and q (t-bit exponents,
+    window capped at 20: sc_dgk_key_create).  Rows are limb form: 29-bit limbs in 32-bit words, the configuration's S = G L limbs."""
+    def row_bytes(bits):
+        for cap, limbs in ((522, 18), (1044, 36), (1566, 54), (2088, 72), (3132, 108), (4176, 144), (6264, 216), (8352, 288)):
+            if bits + 8 <= cap:
+                return 4 * limbs
+        raise ValueError(f"no configuration for a {bits}-bit modulus")
+
+    nwin = lambda bits, w: -(-bits // w)  # noqa: E731
+    total = nwin(rbits, window) * (1 << window) * row_bytes(dgk_bits)
+    if keyholder_crt:
+        w2 = min(window, 20)
+        total += 2 * nwin(t_bits, w2) * (1 << w2) * row_bytes(dgk_bits // 2)
+    else:
+        total *= 2                      # a key holder without CRT builds the same table for h modulo n as Alice
+    return total
+
+
+def choose_fixed_base_window(requested: int, free_bytes: int | None, rbits: int, dgk_bits: int, t_bits: int, keyholder_crt: bool = True,
+                             keep_free_fraction: float = 0.25):
+    """(window, note): the requested window when its tables fit the GPU's FREE memory with room to spare for the batch itself (a
+    quarter of the free bytes stays untouched), else the largest smaller window that does -- never silently: the note goes into
+    the line.  free_bytes None (no way to ask): the requested window."""
+    if free_bytes is None:
+        return requested, None
+    budget = free_bytes * (1.0 - keep_free_fraction)
+    need = fixed_base_table_bytes(requested, rbits, dgk_bits, t_bits, keyholder_crt)
+    if need <= budget:
+        return requested, None
+    for w in range(requested - 1, 0, -1):
+        if w > 16 and w != 20:
+            continue                    # the measured points: 20, 16, then whatever fits
+        got = fixed_base_table_bytes(w, rbits, dgk_bits, t_bits, keyholder_crt)
+        if got <= budget:
+            return w, (f"fixed-base window {requested} needs {need / 2**30:.1f} GiB of tables, the GPU has {free_bytes / 2**30:.1f} GiB free "
+                       f"(a quarter of that stays free for the batch): fell back to window {w} ({got / 2**30:.2f} GiB)")
+    raise SystemExit(f"bench.py: not even a window-1 fixed-base table fits the {free_bytes} free bytes of this GPU")
+
+
 def synth_inputs(eng, l, alice_p, bob_p, bob_d, B, rbits, seed, shuffle=False):
     """Seeded synthetic batch, generated on the device (SURVEY 8(d) 'Synthetic inputs').  shuffle: also draw the step-4i
     permutation of every comparison (SC/initiator.py:516, do_shuffle=True)."""
@@ -141,6 +182,33 @@ def export_sample(path, eng, idx, l, x_enc, y_enc, draws, result):
            "rho_zeta_2": rows(draws.rho_zeta_2), "rho_delta_b": rows(draws.rho_delta_b), "gpu_result": rows(result)}
     with open(path, "w") as f:
         json.dump(doc, f)
+
+
+def cpu_interpreter() -> str:
+    """The interpreter the CPU oracle runs under: the one that has gmpy2 (the reference's optional fast path) when there is one."""
+    return "/opt/conda/bin/python3.9" if os.path.exists("/opt/conda/bin/python3.9") else sys.executable
+
+
+def run_cpu_oracle(interp: str, count: int, procs: int, pname: str, dgk_name: str, rbits: int, sample_path: str | None = None) -> dict:
+    """oracle/cpu_baseline.py in a child process (the CHECKER and the reported CPU baseline; never the thing measured as `value`)."""
+    cp = subprocess.run([interp, os.path.join(ROOT, "oracle", "cpu_baseline.py"), KEYS, pname, dgk_name, str(count), str(procs), str(rbits)] +
+                        ([sample_path] if sample_path else []), capture_output=True, text=True, timeout=900)
+    if cp.returncode != 0:
+        raise RuntimeError(cp.stderr.strip().splitlines()[-1] if cp.stderr.strip() else "cpu baseline failed")
+    return json.loads(cp.stdout.strip().splitlines()[-1])
+
+
+def oracle_rows_check(eng, rows: int, B: int, l: int, x_enc, y_enc, draws, res, pname: str, dgk_name: str, rbits: int) -> dict:
+    """`rows` evenly spaced rows of the resident batch (inputs, every draw, the GPU's results) re-run by the oracle: how many of its
+    results equal the GPU's bit for bit."""
+    cores = min(os.cpu_count() or 1, 16)
+    stride = max(1, B // rows)
+    idx = [i * stride for i in range(min(rows, B))]
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "sample.json")
+        export_sample(path, eng, idx, l, x_enc, y_enc, draws, res)
+        cb = run_cpu_oracle(cpu_interpreter(), len(idx), cores, pname, dgk_name, rbits, path)
+    return {"rows": cb["count"], "equal_to_oracle": cb["match_gpu"], "arith": cb["arith"], "cpu_value": cb["value"], "cores": cb["cores"]}
 
 
 def interactive_protocol_leg(torch, eng, parties, ns, shard_inputs, x_enc, y_enc, expect, l, B, headline, more_parties=None):
@@ -332,10 +400,13 @@ def latency_single_leg(torch, eng, keys):
     bob_p = Paillier(p * q, p, q, engine=eng)
     bob_d = DGK(H("p") * H("q"), H("g"), H("h"), H("u"), dj["t"], H("p"), H("q"), H("v_p"), H("v_q"), engine=eng, randomizer_bits=400)
 
-    def once(fused: bool):
+    def once(fused):
         comm = InMemoryCommunicator()
         alice, bob = Initiator(l, comm, "keyholder"), KeyHolder(l, comm.peer(), "initiator", bob_p, bob_d)
-        alice.fuse_steps = bob.fuse_steps = fused
+        # True: the default path (steps as batch launches through the session coalescer, here a batch of one); "alone": the same five
+        # step-level calls without the coalescer (round 4's default); False: one launch per ciphertext operator
+        alice.fuse_steps = bob.fuse_steps = bool(fused)
+        alice.coalesce_sessions = bob.coalesce_sessions = fused is True
 
         async def go():
             res, _ = await asyncio.gather(alice.perform_secure_comparison(23, 42), bob.perform_secure_comparison())
@@ -347,12 +418,13 @@ def latency_single_leg(torch, eng, keys):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) * 1e3, bob_p.decrypt(res) == 1
 
-    def median_ms(fused: bool, reps: int):
+    def median_ms(fused, reps: int):
         once(fused)                                   # programs, tables, allocator
         runs = [once(fused) for _ in range(reps)]
         return statistics.median(t for t, _ in runs), all(ok for _, ok in runs)
 
     fused_ms, ok_f = median_ms(True, 7)
+    alone_ms, ok_a = median_ms("alone", 7)
     oper_ms, ok_o = median_ms(False, 3)
     # the static step chain (README.md:117-141; no randomization) as one five-call batch of one
     alice_p, alice_d = bob_p.public_copy(), bob_d.public_copy()
@@ -374,10 +446,12 @@ def latency_single_leg(torch, eng, keys):
     chain_runs = [chain() for _ in range(7)]
     dec = eng.download(bob_p.decrypt_raw_batch(chain_runs[-1][1]))[0]
     return {"workload": "BASELINE configs[0]: x=23, y=42, l=16, 1024-bit Paillier + 1024-bit DGK, one comparison",
-            "interactive_ms": fused_ms, "interactive_operator_path_ms": oper_ms, "static_step_chain_ms": statistics.median(t for t, _ in chain_runs),
-            "correct": bool(ok_f and ok_o and dec == 1),
-            "note": "interactive_ms: both players' perform_secure_comparison over the in-memory transport, steps as five library calls on one-element "
-                    "batches, every randomizer generated inside the call -- the key holder's three Paillier randomizers in the background on a second context, "
+            "interactive_ms": fused_ms, "interactive_uncoalesced_ms": alone_ms, "interactive_operator_path_ms": oper_ms,
+            "static_step_chain_ms": statistics.median(t for t, _ in chain_runs),
+            "correct": bool(ok_f and ok_a and ok_o and dec == 1),
+            "note": "interactive_ms: both players' perform_secure_comparison over the in-memory transport through the default path -- the session coalescer "
+                    "with one session in flight, i.e. five library calls on one-element batches with the randomizations fused into them; interactive_uncoalesced_ms: "
+                    "round 4's default, the same five calls with the randomizers popped from the schemes' pools; every randomizer generated inside the call -- the key holder's three Paillier randomizers in the background on a second context, "
                     "like the reference's background workers (KeyHolder.background_randomness; 11.9 ms without) -- (median of 7 after a warm-up run); interactive_operator_path_ms: the same "
                     "exchange with one launch per ciphertext operator (Initiator.fuse_steps = False), identical ciphertexts; static_step_chain_ms: "
                     "steps 1-7 without randomization as a batch of one.  A single comparison is a chain of dependent launches on an otherwise idle "
@@ -535,6 +609,11 @@ class GpuRuntime:
     def cu_count(self, eng) -> int:
         return self.torch.cuda.get_device_properties(eng.device).multi_processor_count
 
+    def free_memory(self, eng) -> int | None:
+        """Free device bytes right now (every rank of a node asks its own GPU before it builds its tables)."""
+        free, _total = self.torch.cuda.mem_get_info(eng.device)
+        return int(free)
+
     def default_engine(self):
         from protocols.secure_comparison_amd.schemes import default_engine
 
@@ -656,6 +735,11 @@ def measure(args, torch, dist, rank: int, world: int, full: bool, rt=None):
             sets[i].side = PartySet(alice_pai, alice_d, bob_p, bob_d, rt.stream())
         return sets, build_s, table_bytes
 
+    requested_window = args.fb_window
+    args.fb_window, window_note = choose_fixed_base_window(requested_window, rt.free_memory(eng) if hasattr(rt, "free_memory") else None, args.rbits, dbits,
+                                                           dj["t"], use_crt)
+    if window_note and rank == 0:
+        print("bench.py: " + window_note, file=sys.stderr, flush=True)
     parties, table_build_s, table_bytes = build_parties(args.fb_window)
     alice_p, alice_d, bob_p, bob_d = parties[0].alice_paillier, parties[0].alice_dgk, parties[0].bob_paillier, parties[0].bob_dgk
     x, y, x_enc, y_enc, draws = synth_inputs(eng, l, alice_p, bob_p, bob_d, B, args.rbits, seed=rank, shuffle=not args.no_shuffle)
@@ -741,7 +825,7 @@ def measure(args, torch, dist, rank: int, world: int, full: bool, rt=None):
     # ---- diagnostics BEFORE anything else has loaded the chip (rank 0 of the headline run): the dominant launch, the probe and the
     # in-kernel clock -- repeated after the timed loop, so that the line itself says whether the chip's clock state moved
     diag_before = None
-    if full and rank == 0:
+    if full:       # every rank: with N GPUs the slowest one sets a weak-scaling step, and the line must be able to say which it was
         ls_, _, pk_ = dominant_launch(reps=2)
         diag_before = {"launch_ms": ls_ * 1e3, "probe_peak": pk_ / 1e12, "clock_ghz": clock_ghz()}
 
@@ -776,6 +860,35 @@ def measure(args, torch, dist, rank: int, world: int, full: bool, rt=None):
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1))
     if not all_correct(res):
         raise SystemExit("bench.py: decrypted results of the timed steps differ from x <= y")
+    # ---- per-rank view (outside the timed region): this rank's step WITHOUT the collective (what its GPU does alone), its dominant
+    # launch, probe and clock before / after -- gathered into rank 0's line with one small all-gather
+    per_rank, weak_eff = None, None
+    if full:
+        solo_marks = [rt.event() for _ in range(3)]
+        solo_marks[0].record()
+        for i_ in range(2):
+            step()
+            solo_marks[i_ + 1].record()
+        rt.synchronize()
+        solo_ms = min(solo_marks[i_].elapsed_time(solo_marks[i_ + 1]) for i_ in range(2))
+        la_, _, pa_ = dominant_launch(reps=2)
+        ck_ = clock_ghz()
+        mine = [float(rank), float(rt.current_device()), step_ms[len(step_ms) // 2], step_ms[0], step_ms[-1], solo_ms, diag_before["launch_ms"], la_ * 1e3,
+                diag_before["clock_ghz"] or 0.0, ck_ or 0.0, diag_before["probe_peak"], pa_ / 1e12, float(table_bytes), float(args.fb_window)]
+        rows_ = [mine]
+        if dist is not None:
+            dev_ = eng.device if rt.backend == "nccl" else "cpu"
+            buf_ = torch.zeros(world * len(mine), dtype=torch.float64, device=dev_)       # (flat: gloo's gather wants the concatenated form)
+            dist.all_gather_into_tensor(buf_, torch.tensor(mine, dtype=torch.float64, device=dev_))
+            rows_ = buf_.reshape(world, len(mine)).cpu().tolist()
+        names_ = ("rank", "device", "step_ms_median", "step_ms_min", "step_ms_max", "solo_step_ms", "launch_ms_before", "launch_ms_after", "clock_ghz_before",
+                  "clock_ghz_after", "probe_peak_before", "probe_peak_after", "fixed_base_table_bytes", "fixed_base_window")
+        per_rank = [dict(zip(names_, r_)) for r_ in rows_]
+        for pr_ in per_rank:
+            pr_["rank"], pr_["device"], pr_["fixed_base_window"] = int(pr_["rank"]), int(pr_["device"]), int(pr_["fixed_base_window"])
+            pr_["fixed_base_table_bytes"] = int(pr_["fixed_base_table_bytes"])
+        slowest = max(pr_["solo_step_ms"] for pr_ in per_rank)
+        weak_eff = value / (world * B / (slowest * 1e-3))
     close_step()      # the single-stream measurements below run with the policies of a context that has the chip to itself
     nominal_peak = cus * 64 * MAX_CLOCK_HZ   # 4 SIMDs x 16 lanes per CU, one multiply-add per lane and cycle
     if not full:      # a compact sub-line of another BASELINE shape
@@ -784,6 +897,14 @@ def measure(args, torch, dist, rank: int, world: int, full: bool, rt=None):
             sub = {"workload": workload_name(B, l, args.pbits, dbits), "value": value, "unit": "comparisons/s", "ms_per_step": elapsed / args.steps * 1e3,
                    "steps": args.steps, "streams_per_gpu": ns, "randomizers_on_side_stream": use_side, "dgk_key": dname,
                    "whole_step_frac": executed_macs / (elapsed * nominal_peak), "all_rows_decrypt_to_x_le_y": True}
+            if not args.no_cpu_baseline:     # like the headline: rows of the timed batch under the oracle, bit for bit (round 4 held these to the decrypt property)
+                try:
+                    mine_ = (res[rank * B:(rank + 1) * B] if world > 1 else res).contiguous()
+                    sub["oracle"] = oracle_rows_check(eng, 64, B, l, x_enc, y_enc, draws, mine_, f"paillier_{args.pbits}", dname, args.rbits)
+                except Exception as exc:  # pragma: no cover
+                    sub["oracle"] = {"error": str(exc)[:200]}
+                if sub["oracle"].get("equal_to_oracle") != sub["oracle"].get("rows"):
+                    raise SystemExit(f"bench.py: the CPU oracle and the GPU disagree on sampled rows of {sub['workload']}: {sub['oracle']}")
         del parties, step, close_step
         for e_ in engines + side_engines:
             e_.close()
@@ -843,9 +964,16 @@ def measure(args, torch, dist, rank: int, world: int, full: bool, rt=None):
             "data": "synthetic", "rccl_ranks": rccl_ranks, "rank_devices": devices, "c_abi_gather": c_abi_gather,
             "step_ms": {"min": step_ms[0], "median": step_ms[len(step_ms) // 2], "max": step_ms[-1],
                         "note": "per-step device time between events on the caller's stream inside the timed region (no synchronisation added)"},
+            "per_rank": per_rank,
+            "weak_scaling_efficiency": weak_eff,
+            "per_rank_note": "one row per rank, gathered outside the timed region: its steps inside the timed loop (median / min / max, collective included), "
+                             "its step WITHOUT the collective (solo_step_ms, best of two), its dominant launch, in-kernel clock and multiply-add probe before the "
+                             "warm-up and after the loop, its table; weak_scaling_efficiency = value / (N x B / slowest rank's solo step): what the collective "
+                             "and the slowest GPU cost together",
             "config": {"workload": workload_name(B, l, args.pbits, dbits),
                        "batch_per_gpu": B, "l": l, "paillier_bits": args.pbits, "dgk_bits": dbits, "dgk_key": dname, "dgk_randomizer_bits": args.rbits,
-                       "fixed_base_window": args.fb_window, "keyholder_crt": use_crt, "shuffle_4i": not args.no_shuffle,
+                       "fixed_base_window": args.fb_window, "fixed_base_window_requested": requested_window, "fixed_base_window_note": window_note,
+                       "keyholder_crt": use_crt, "shuffle_4i": not args.no_shuffle,
                        "parallelism": "shard%d" % world, "streams_per_gpu": ns, "randomizers_on_side_stream": use_side,
                        "fixed_base_table_bytes": table_bytes, "table_build_s": table_build_s,
                        "table_note": "device bytes of Alice's table for h mod n plus the key holder's CRT tables for h mod p, h mod q, built once per GPU "
@@ -891,7 +1019,7 @@ def measure(args, torch, dist, rank: int, world: int, full: bool, rt=None):
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N = 1 only
             cores = min(os.cpu_count() or 1, 16)
             sample = min(B, args.cpu_sample or 64 * cores)
-            py = "/opt/conda/bin/python3.9" if os.path.exists("/opt/conda/bin/python3.9") else sys.executable
+            py = cpu_interpreter()
             py_cpu, cores_cpu = py, cores
             try:
                 stride = max(1, B // sample)
@@ -901,12 +1029,7 @@ def measure(args, torch, dist, rank: int, world: int, full: bool, rt=None):
                     export_sample(path, eng, idx, l, x_enc, y_enc, draws, res)
 
                     def cpu_run(interp, count, procs, pname=f"paillier_{args.pbits}", dgk_name=dname, sample_path=path):
-                        cp = subprocess.run([interp, os.path.join(ROOT, "oracle", "cpu_baseline.py"), KEYS, pname, dgk_name,
-                                             str(count), str(procs), str(args.rbits)] + ([sample_path] if sample_path else []),
-                                            capture_output=True, text=True, timeout=900)
-                        if cp.returncode != 0:
-                            raise RuntimeError(cp.stderr.strip().splitlines()[-1] if cp.stderr.strip() else "cpu baseline failed")
-                        return json.loads(cp.stdout.strip().splitlines()[-1])
+                        return run_cpu_oracle(interp, count, procs, pname, dgk_name, args.rbits, sample_path)
 
                     cb = cpu_run(py, sample, cores)
                     out["cpu_baseline"] = {"value": cb["value"], "unit": "comparisons/s", "cores": cb["cores"], "kind": "port",

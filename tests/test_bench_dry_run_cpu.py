@@ -36,6 +36,35 @@ def test_two_ranks_started_by_bench_itself():
     # value = the comparisons of ALL ranks over the slowest rank's time
     assert abs(d["value"] - 2 * 3 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"]
     assert len(d["step_ms"]) >= 3 and "cpu_baseline" not in d and "interactive_protocol" not in d
+    # one diagnostic row per rank (its own steps, its step without the collective, launch / clock / probe before and after, its table)
+    assert [r["rank"] for r in d["per_rank"]] == [0, 1] and [r["device"] for r in d["per_rank"]] == [0, 1]
+    for r in d["per_rank"]:
+        assert r["solo_step_ms"] > 0 and r["step_ms_min"] <= r["step_ms_median"] <= r["step_ms_max"] and r["fixed_base_window"] == 4
+        assert r["launch_ms_before"] > 0 and r["launch_ms_after"] > 0 and r["fixed_base_table_bytes"] > 0
+    slowest = max(r["solo_step_ms"] for r in d["per_rank"])
+    assert abs(d["weak_scaling_efficiency"] - d["value"] / (2 * 3 / (slowest * 1e-3))) < 1e-9 * d["value"] + 1e-9
+
+
+def test_table_window_falls_back_when_the_gpu_is_short_of_memory():
+    """Every rank asks its GPU for its FREE memory before building the fixed-base tables: a window whose tables do not fit (with a
+    quarter of the free bytes left for the batch) is replaced by the largest smaller one that does, and the line says so."""
+    import bench
+
+    full = bench.fixed_base_table_bytes(20, 400, 2048, 160)
+    assert full == 8455716864                                   # what round 4's line reports for window 20 (Alice's table + the CRT halves)
+    assert bench.choose_fixed_base_window(20, 288 << 30, 400, 2048, 160) == (20, None)
+    w, note = bench.choose_fixed_base_window(20, 9 << 30, 400, 2048, 160)
+    assert w == 16 and "fell back to window 16" in note
+    assert bench.choose_fixed_base_window(24, 90 << 30, 400, 2048, 160)[0] == 20
+    assert bench.choose_fixed_base_window(20, None, 400, 2048, 160) == (20, None)
+    env = _clean_env()
+    env["SC_DRY_FREE_BYTES"] = "30000"                           # the whole dry run on a "GPU" with 30 000 free bytes: the tiny key's window-4 tables (26 KB) do not fit
+    args = [a for a in ARGS]
+    cp = subprocess.run([sys.executable, DRY, "--gpus", "1"] + args, env=env, capture_output=True, text=True, timeout=600)
+    assert cp.returncode == 0, cp.stderr[-2000:]
+    d = _line(cp.stdout)
+    assert d["config"]["fixed_base_window_requested"] == 4 and d["config"]["fixed_base_window"] < 4 and "fell back" in d["config"]["fixed_base_window_note"]
+    assert "fell back" in cp.stderr
 
 
 def test_two_ranks_under_a_launcher_environment():
