@@ -8,12 +8,12 @@ import os as _os
 # more; every context that generates randomizers in the background is another.  Read by the runtime when it initialises, i.e. at the first GPU call of the process; an exported value wins.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
-from .communicator import Communicator, InMemoryCommunicator
+from .communicator import Communicator, InMemoryCommunicator, StreamCommunicator
 from .initiator import AlicePlain, Initiator
 from .keyholder import BobPlain, KeyHolder
 from .schemes import DGK, DGKCiphertext, Paillier, PaillierCiphertext
 from .utils import from_bits, to_bits
 
-__all__ = ["Communicator", "InMemoryCommunicator", "Initiator", "KeyHolder", "from_bits", "to_bits", "Paillier", "PaillierCiphertext", "DGK",
+__all__ = ["Communicator", "InMemoryCommunicator", "StreamCommunicator", "Initiator", "KeyHolder", "from_bits", "to_bits", "Paillier", "PaillierCiphertext", "DGK",
            "DGKCiphertext", "AlicePlain", "BobPlain"]
 __version__ = "0.1.0"

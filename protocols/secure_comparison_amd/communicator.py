@@ -8,6 +8,7 @@ and messages are keyed by their ``msg_id`` (the session-numbered step names keep
 from __future__ import annotations
 
 import asyncio
+import struct
 from typing import Any, Protocol, runtime_checkable
 
 
@@ -89,6 +90,80 @@ class InMemoryCommunicator:
                 del left[msg_id]
                 if not left:
                     del self.mailbox[_WAITERS]
+
+
+class StreamCommunicator:
+    """Bytes over one asyncio stream pair (a Unix or TCP socket): the minimal transport between two PROCESSES -- the reference's
+    players live in separate processes or hosts (SC/test/integration/test_pool.py:41-73, over tno.mpc.communication's HTTP pools,
+    which are out of scope here).  Frames are `id length u32 | id | payload length u64 | payload`; a reader task files arriving
+    frames under their message ids, so concurrent sub-sessions (chunked batches) share the connection.  Carries what the batch
+    protocol puts on a byte transport (wire.py) and JSON scheme documents; ciphertext OBJECTS of the single-comparison protocol need
+    a serializer of their own and are refused."""
+
+    device_tensors = False
+
+    def __init__(self, reader: asyncio.StreamReader, writer: asyncio.StreamWriter, timeout_s: float | None = 600.0) -> None:
+        self.reader, self.writer, self.timeout_s = reader, writer, timeout_s
+        self._box: dict[str, Any] = {}
+        self._waiters: dict[str, asyncio.Future] = {}
+        self._pump: asyncio.Task | None = None
+        self._closed: BaseException | None = None
+
+    async def _read_frames(self) -> None:
+        try:
+            while True:
+                (n,) = struct.unpack("<I", await self.reader.readexactly(4))
+                if n > 4096:
+                    raise ValueError("malformed frame (message id length)")
+                msg_id = (await self.reader.readexactly(n)).decode()
+                (size,) = struct.unpack("<Q", await self.reader.readexactly(8))
+                payload = await self.reader.readexactly(size)
+                fut = self._waiters.pop(msg_id, None)
+                if fut is not None and not fut.done():
+                    fut.set_result(payload)
+                else:
+                    self._box[msg_id] = payload
+        except (asyncio.IncompleteReadError, ConnectionError, ValueError) as exc:
+            self._closed = exc
+            for fut in self._waiters.values():
+                if not fut.done():
+                    fut.set_exception(ConnectionError(f"connection closed while waiting: {exc!r}"))
+            self._waiters.clear()
+
+    async def send(self, party_id: str, message: Any, msg_id: str) -> None:
+        try:
+            payload = memoryview(message).cast("B")
+        except TypeError:
+            raise TypeError(f"StreamCommunicator carries bytes (batch messages, scheme documents), not {type(message).__name__}") from None
+        ident = msg_id.encode()
+        self.writer.write(struct.pack("<I", len(ident)) + ident + struct.pack("<Q", len(payload)))
+        self.writer.write(payload)
+        await self.writer.drain()
+
+    async def recv(self, party_id: str, msg_id: str) -> Any:
+        if self._pump is None:
+            self._pump = asyncio.ensure_future(self._read_frames())
+        if msg_id in self._box:
+            return self._box.pop(msg_id)
+        if self._closed is not None:
+            raise ConnectionError(f"connection closed: {self._closed!r}")
+        fut = asyncio.get_running_loop().create_future()
+        self._waiters[msg_id] = fut
+        try:
+            return await (fut if self.timeout_s is None else asyncio.wait_for(fut, self.timeout_s))
+        except asyncio.TimeoutError:
+            raise TimeoutError(f"no message {msg_id!r} from {party_id!r}") from None
+        finally:
+            self._waiters.pop(msg_id, None)
+
+    async def close(self) -> None:
+        if self._pump is not None:
+            self._pump.cancel()
+        self.writer.close()
+        try:
+            await self.writer.wait_closed()
+        except Exception:  # noqa: BLE001 -- the peer may be gone already
+            pass
 
 
 def _check_deadlines(comm: "InMemoryCommunicator", loop) -> None:

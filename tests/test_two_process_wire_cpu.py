@@ -85,3 +85,79 @@ def test_two_processes_bytes_only(keys):
         if child.is_alive():
             child.kill()
     assert child.exitcode == 0
+
+
+def _keyholder_over_a_socket(path, root, batches):
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import json
+
+    from _oracle_engine import OracleEngine
+    from conftest import oracle_dgk as od_, oracle_paillier as op_
+    from protocols.secure_comparison_amd import DGK, KeyHolder, Paillier, StreamCommunicator
+
+    keys = json.load(open(os.path.join(root, "tests", "golden", "keys.json")))
+    osk, od = op_(keys, 1024), od_(keys, "dgk_tiny_l16")
+    eng = OracleEngine()
+
+    async def serve():
+        done = asyncio.Event()
+
+        async def on_connect(reader, writer):
+            comm = StreamCommunicator(reader, writer)
+            bob = KeyHolder(L, comm, "alice", Paillier(osk.n, osk.p, osk.q, engine=eng),
+                            DGK(od.n, od.g, od.h, od.u, od.t, od.p, od.q, od.v_p, od.v_q, engine=eng, randomizer_bits=50))
+            for _ in range(batches):
+                await bob.perform_secure_comparison_batch()
+            await comm.close()
+            done.set()
+
+        server = await asyncio.start_unix_server(on_connect, path=path)
+        async with server:
+            await asyncio.wait_for(done.wait(), 120)
+
+    asyncio.run(serve())
+
+
+def test_two_processes_over_a_socket(keys, tmp_path):
+    """The same exchange over communicator.StreamCommunicator (asyncio streams on a Unix socket): the transport the GPU-box tool
+    tools/gpu_two_process.py uses.  Chunked sub-sessions interleave their frames on the one connection."""
+    from _oracle_engine import OracleEngine
+    from protocols.secure_comparison_amd import Initiator, StreamCommunicator
+
+    osk, od = oracle_paillier(keys, 1024), oracle_dgk(keys, "dgk_tiny_l16")
+    path = str(tmp_path / "sc.sock")
+    ctx = mp.get_context("spawn")
+    child = ctx.Process(target=_keyholder_over_a_socket, args=(path, ROOT, 2), daemon=True)
+    child.start()
+    eng = OracleEngine()
+    rng = random.Random(23)
+
+    async def go():
+        for _ in range(200):                                     # the child needs a moment to listen
+            if os.path.exists(path):
+                break
+            await asyncio.sleep(0.05)
+        reader, writer = await asyncio.open_unix_connection(path)
+        comm = StreamCommunicator(reader, writer)
+        alice = Initiator(L, comm, "bob")
+        out = []
+        for B, chunks in ((5, 1), (9, 3)):
+            xs = [rng.randrange(1 << L) for _ in range(B)]
+            ys = [xs[i] if i % 4 == 0 else rng.randrange(1 << L) for i in range(B)]
+            tx, ty = eng.upload([osk.enc_raw(x) for x in xs], 64), eng.upload([osk.enc_raw(y) for y in ys], 64)
+            res = await alice.perform_secure_comparison_batch(tx, ty, engine=eng, chunks=chunks)
+            out.append(([osk.dec_raw(v) for v in eng.download(res)], [int(x <= y) for x, y in zip(xs, ys)]))
+        with pytest.raises(TypeError):
+            await comm.send("bob", object(), "not bytes")
+        await comm.close()
+        return out
+
+    try:
+        for got, want in asyncio.run(go()):
+            assert got == want
+    finally:
+        child.join(60)
+        if child.is_alive():
+            child.kill()
+    assert child.exitcode == 0
