@@ -93,37 +93,96 @@ class InMemoryCommunicator:
 
 
 class StreamCommunicator:
-    """Bytes over one asyncio stream pair (a Unix or TCP socket): the minimal transport between two PROCESSES -- the reference's
-    players live in separate processes or hosts (SC/test/integration/test_pool.py:41-73, over tno.mpc.communication's HTTP pools,
-    which are out of scope here).  Frames are `id length u32 | id | payload length u64 | payload`; a reader task files arriving
-    frames under their message ids, so concurrent sub-sessions (chunked batches) share the connection.  Carries what the batch
-    protocol puts on a byte transport (wire.py) and JSON scheme documents; ciphertext OBJECTS of the single-comparison protocol need
-    a serializer of their own and are refused."""
+    """Bytes over one connected socket (Unix or TCP): the minimal transport between two PROCESSES -- the reference's players live in
+    separate processes or hosts (SC/test/integration/test_pool.py:41-73, over tno.mpc.communication's HTTP pools, which are out of
+    scope here).  Frames are `id length u32 | id | payload length u64 | payload`; a reader task files arriving frames under their
+    message ids, so concurrent sub-sessions (chunked batches) share the connection.  Payloads go out with `loop.sock_sendall`
+    straight from the sender's buffer (the pinned message the kernels wrote, wire.reserve) and are received with
+    `loop.sock_recv_into` into a buffer from `alloc(nbytes)` -- hand in wire.pinned_buffer and a batch message lands in pinned host
+    memory, from where the host-to-device copies run on an SDMA engine without a staging copy.  Carries what the batch protocol puts
+    on a byte transport (wire.py) and JSON scheme documents; ciphertext OBJECTS of the single-comparison protocol need a serializer
+    of their own and are refused."""
 
     device_tensors = False
 
-    def __init__(self, reader: asyncio.StreamReader, writer: asyncio.StreamWriter, timeout_s: float | None = 600.0) -> None:
-        self.reader, self.writer, self.timeout_s = reader, writer, timeout_s
+    def __init__(self, sock, alloc=None, timeout_s: float | None = 600.0) -> None:
+        sock.setblocking(False)
+        self.sock, self.timeout_s = sock, timeout_s
+        self._alloc = alloc if alloc is not None else bytearray
         self._box: dict[str, Any] = {}
         self._waiters: dict[str, asyncio.Future] = {}
         self._pump: asyncio.Task | None = None
         self._closed: BaseException | None = None
+        self._send_lock: asyncio.Lock | None = None
+
+    @classmethod
+    async def open_unix(cls, path: str, alloc=None, wait_s: float = 60.0) -> "StreamCommunicator":
+        """Connect to a listening Unix socket (waiting for the peer to start listening)."""
+        import os
+        import socket
+
+        loop, t_end = asyncio.get_running_loop(), asyncio.get_running_loop().time() + wait_s
+        while True:
+            sock = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+            sock.setblocking(False)
+            try:
+                if not os.path.exists(path):
+                    raise FileNotFoundError(path)
+                await loop.sock_connect(sock, path)
+                return cls(sock, alloc)
+            except (FileNotFoundError, ConnectionRefusedError):
+                sock.close()
+                if loop.time() > t_end:
+                    raise
+                await asyncio.sleep(0.05)
+
+    @classmethod
+    async def accept_unix(cls, path: str, alloc=None) -> "StreamCommunicator":
+        """Listen on a Unix socket and return the communicator of the first connection."""
+        import socket
+
+        srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        srv.bind(path)
+        srv.listen(1)
+        srv.setblocking(False)
+        try:
+            conn, _ = await asyncio.get_running_loop().sock_accept(srv)
+        finally:
+            srv.close()
+        return cls(conn, alloc)
+
+    async def _read_exact(self, loop, view: memoryview) -> None:
+        got = 0
+        while got < len(view):
+            n = await loop.sock_recv_into(self.sock, view[got:])
+            if n == 0:
+                raise ConnectionError("peer closed the connection")
+            got += n
 
     async def _read_frames(self) -> None:
+        loop = asyncio.get_running_loop()
+        head = bytearray(4)
         try:
             while True:
-                (n,) = struct.unpack("<I", await self.reader.readexactly(4))
+                await self._read_exact(loop, memoryview(head))
+                (n,) = struct.unpack("<I", head)
                 if n > 4096:
                     raise ValueError("malformed frame (message id length)")
-                msg_id = (await self.reader.readexactly(n)).decode()
-                (size,) = struct.unpack("<Q", await self.reader.readexactly(8))
-                payload = await self.reader.readexactly(size)
+                rest = bytearray(n + 8)
+                await self._read_exact(loop, memoryview(rest))
+                msg_id = bytes(rest[:n]).decode()
+                (size,) = struct.unpack("<Q", rest[n:])
+                if size > (1 << 40):
+                    raise ValueError("malformed frame (payload length)")
+                payload = self._alloc(size)
+                if size:
+                    await self._read_exact(loop, memoryview(payload).cast("B"))
                 fut = self._waiters.pop(msg_id, None)
                 if fut is not None and not fut.done():
                     fut.set_result(payload)
                 else:
                     self._box[msg_id] = payload
-        except (asyncio.IncompleteReadError, ConnectionError, ValueError) as exc:
+        except (ConnectionError, OSError, ValueError) as exc:
             self._closed = exc
             for fut in self._waiters.values():
                 if not fut.done():
@@ -135,10 +194,14 @@ class StreamCommunicator:
             payload = memoryview(message).cast("B")
         except TypeError:
             raise TypeError(f"StreamCommunicator carries bytes (batch messages, scheme documents), not {type(message).__name__}") from None
+        loop = asyncio.get_running_loop()
+        if self._send_lock is None:
+            self._send_lock = asyncio.Lock()
         ident = msg_id.encode()
-        self.writer.write(struct.pack("<I", len(ident)) + ident + struct.pack("<Q", len(payload)))
-        self.writer.write(payload)
-        await self.writer.drain()
+        async with self._send_lock:                      # frames of concurrent sub-sessions must not interleave
+            await loop.sock_sendall(self.sock, struct.pack("<I", len(ident)) + ident + struct.pack("<Q", len(payload)))
+            if len(payload):
+                await loop.sock_sendall(self.sock, payload)
 
     async def recv(self, party_id: str, msg_id: str) -> Any:
         if self._pump is None:
@@ -159,11 +222,11 @@ class StreamCommunicator:
     async def close(self) -> None:
         if self._pump is not None:
             self._pump.cancel()
-        self.writer.close()
-        try:
-            await self.writer.wait_closed()
-        except Exception:  # noqa: BLE001 -- the peer may be gone already
-            pass
+            try:
+                await self._pump
+            except (asyncio.CancelledError, Exception):  # noqa: BLE001
+                pass
+        self.sock.close()
 
 
 def _check_deadlines(comm: "InMemoryCommunicator", loop) -> None:

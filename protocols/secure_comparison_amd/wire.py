@@ -114,6 +114,15 @@ class _PinnedPool:
 
 
 _pinned_pool = _PinnedPool()
+
+
+def pinned_buffer(nbytes: int):
+    """A writable buffer of `nbytes` bytes of PINNED host memory from the message pool (returned to the pool when nothing refers to
+    it any more): what a receiving transport reads a batch message into, so that the host-to-device copies of `incoming` need no
+    staging copy (communicator.StreamCommunicator(alloc=wire.pinned_buffer))."""
+    if nbytes < (1 << 16):
+        return bytearray(nbytes)                      # scheme documents, plans: not worth a pinned block
+    return _pinned_pool.take(nbytes)[1]
 _copy_streams: dict = {}
 
 

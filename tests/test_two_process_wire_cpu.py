@@ -101,26 +101,18 @@ def _keyholder_over_a_socket(path, root, batches):
     eng = OracleEngine()
 
     async def serve():
-        done = asyncio.Event()
-
-        async def on_connect(reader, writer):
-            comm = StreamCommunicator(reader, writer)
-            bob = KeyHolder(L, comm, "alice", Paillier(osk.n, osk.p, osk.q, engine=eng),
-                            DGK(od.n, od.g, od.h, od.u, od.t, od.p, od.q, od.v_p, od.v_q, engine=eng, randomizer_bits=50))
-            for _ in range(batches):
-                await bob.perform_secure_comparison_batch()
-            await comm.close()
-            done.set()
-
-        server = await asyncio.start_unix_server(on_connect, path=path)
-        async with server:
-            await asyncio.wait_for(done.wait(), 120)
+        comm = await asyncio.wait_for(StreamCommunicator.accept_unix(path), 120)
+        bob = KeyHolder(L, comm, "alice", Paillier(osk.n, osk.p, osk.q, engine=eng),
+                        DGK(od.n, od.g, od.h, od.u, od.t, od.p, od.q, od.v_p, od.v_q, engine=eng, randomizer_bits=50))
+        for _ in range(batches):
+            await bob.perform_secure_comparison_batch()
+        await comm.close()
 
     asyncio.run(serve())
 
 
 def test_two_processes_over_a_socket(keys, tmp_path):
-    """The same exchange over communicator.StreamCommunicator (asyncio streams on a Unix socket): the transport the GPU-box tool
+    """The same exchange over communicator.StreamCommunicator (a Unix socket driven by the event loop): the transport the GPU-box tool
     tools/gpu_two_process.py uses.  Chunked sub-sessions interleave their frames on the one connection."""
     from _oracle_engine import OracleEngine
     from protocols.secure_comparison_amd import Initiator, StreamCommunicator
@@ -134,12 +126,7 @@ def test_two_processes_over_a_socket(keys, tmp_path):
     rng = random.Random(23)
 
     async def go():
-        for _ in range(200):                                     # the child needs a moment to listen
-            if os.path.exists(path):
-                break
-            await asyncio.sleep(0.05)
-        reader, writer = await asyncio.open_unix_connection(path)
-        comm = StreamCommunicator(reader, writer)
+        comm = await StreamCommunicator.open_unix(path)            # (waits for the child to listen)
         alice = Initiator(L, comm, "bob")
         out = []
         for B, chunks in ((5, 1), (9, 3)):

@@ -56,23 +56,15 @@ async def keyholder(args):
                 fixed_base_window=args.window)
     bob_d.prepare()
     _ = bob_p.key
-    done = asyncio.Event()
-
-    async def on_connect(reader, writer):
-        comm = StreamCommunicator(reader, writer)
-        bob = KeyHolder(args.l, comm, "initiator", bob_p, bob_d)
-        for _ in range(args.batches + 1):                      # one warm-up batch, then the timed ones
-            await bob.perform_secure_comparison_batch()
-        res, expect = wire.unpack_many(await comm.recv("initiator", "check"), eng.device, expect=2)
-        dec = bob_p.decrypt_raw_batch(res.contiguous())
-        ok = int(((dec[:, 0] == expect.reshape(-1).to(torch.int32)) & (dec[:, 1:] == 0).all(dim=1)).sum().item())
-        await comm.send("initiator", json.dumps({"ok": ok, "rows": int(res.shape[0])}).encode(), "verdict")
-        await comm.close()
-        done.set()
-
-    server = await asyncio.start_unix_server(on_connect, path=args.socket)
-    async with server:
-        await done.wait()
+    comm = await StreamCommunicator.accept_unix(args.socket, alloc=wire.pinned_buffer)       # batch messages land in pinned host memory
+    bob = KeyHolder(args.l, comm, "initiator", bob_p, bob_d)
+    for _ in range(args.batches + 1):                      # one warm-up batch, then the timed ones
+        await bob.perform_secure_comparison_batch()
+    res, expect = wire.unpack_many(await comm.recv("initiator", "check"), eng.device, expect=2)
+    dec = bob_p.decrypt_raw_batch(res.contiguous())
+    ok = int(((dec[:, 0] == expect.reshape(-1).to(torch.int32)) & (dec[:, 1:] == 0).all(dim=1)).sum().item())
+    await comm.send("initiator", json.dumps({"ok": ok, "rows": int(res.shape[0])}).encode(), "verdict")
+    await comm.close()
 
 
 async def initiator(args):
@@ -88,12 +80,7 @@ async def initiator(args):
     pub_d = DGK(d["p"] * d["q"], d["g"], d["h"], d["u"], d["t"], engine=eng, randomizer_bits=400, fixed_base_window=args.window)
     x, y, x_enc, y_enc, _ = bench.synth_inputs(eng, args.l, pub_p, pub_p, pub_d, args.batch, 400, seed=0)
     expect = (x <= y).to(torch.int32)
-    for _ in range(600):
-        if os.path.exists(args.socket):
-            break
-        await asyncio.sleep(0.1)
-    reader, writer = await asyncio.open_unix_connection(args.socket, limit=1 << 26)
-    comm = StreamCommunicator(reader, writer)
+    comm = await StreamCommunicator.open_unix(args.socket, alloc=wire.pinned_buffer, wait_s=300)
     alice = Initiator(args.l, comm, "keyholder")
     await alice.perform_secure_comparison_batch(x_enc, y_enc, engine=eng, chunks=args.chunks)         # warm-up: tables, programs, pinned pools
     torch.cuda.synchronize()
@@ -114,7 +101,7 @@ async def initiator(args):
                       "seconds_per_batch": {"min": per[0], "median": per[len(per) // 2], "max": per[-1]},
                       "wire_bytes_per_comparison_sent_by_the_initiator": wire.STATS["bytes"] / (args.batch * args.batches),
                       "rows_decrypting_to_x_le_y": verdict["ok"], "rows_checked": verdict["rows"],
-                      "transport": "Unix socket, communicator.StreamCommunicator, wire.py byte messages; two OS processes, one GPU, own HIP contexts"}), flush=True)
+                      "transport": "Unix socket, communicator.StreamCommunicator (sendall from / recv_into pinned message buffers), wire.py byte messages; two OS processes, one GPU, own HIP contexts"}), flush=True)
 
 
 def parent(args):
