@@ -22,7 +22,7 @@ import sys
 import tempfile
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")   # before the HIP runtime initialises: see protocols/secure_comparison_amd/__init__.py
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")   # before the HIP runtime initialises: see protocols/secure_comparison_amd/engine.py::_default_hw_queues
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -182,6 +182,18 @@ def export_sample(path, eng, idx, l, x_enc, y_enc, draws, result):
            "rho_zeta_2": rows(draws.rho_zeta_2), "rho_delta_b": rows(draws.rho_delta_b), "gpu_result": rows(result)}
     with open(path, "w") as f:
         json.dump(doc, f)
+
+
+def policy_of(eng) -> dict:
+    """The measured constants behind the library's automatic policies (a calibration the library itself rejected as implausible --
+    the chip was busy -- is reported as such, not raised)."""
+    try:
+        out = dict(eng.policy())
+    except Exception as exc:  # noqa: BLE001
+        out = {"error": str(exc)[:200]}
+    if hasattr(eng, "stats"):
+        out["context_stats"] = eng.stats()
+    return out
 
 
 def cpu_interpreter() -> str:
@@ -1008,7 +1020,7 @@ def measure(args, torch, dist, rank: int, world: int, full: bool, rt=None):
                          "before_after_note": "the dominant launch, the pure multiply-add probe and the in-kernel clock (sc_clock_probe: s_memtime / s_memrealtime stamps of a twin "
                                               "of the kernel, never a timed launch) measured BEFORE the warm-up and AFTER the timed loop: a line whose value moved "
                                               "while these did not has changed code, one where they moved together has a chip in another clock state"},
-            "policy": eng.policy(),
+            "policy": policy_of(eng),
             "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
             "modexp_per_s": {"P": B / launch_s, "D": d_rate,
                              "shapes": "P: %d-bit base ^ %d-bit exponent mod %d-bit (rho^N mod N^2); D: fixed base, %d-bit exponent mod %d-bit (h^r mod n)"

@@ -57,8 +57,9 @@ const char* sc_last_error(sc_ctx* ctx);
  * have no bad_index parameter of their own. */
 int64_t sc_last_bad_index(sc_ctx* ctx);
 /* Bumped whenever an entry point is added, removed or changes meaning; the binding checks it (round 3: 3; round 4: 4 -- the header
- * split into sc_amd.h / sc_amd_dev.h, SC_STEP_DEFER_CHECKS and sc_ctx_check removed, sc_clock_probe and sc_ctx_policy added). */
-#define SC_ABI_VERSION 4
+ * split into sc_amd.h / sc_amd_dev.h, SC_STEP_DEFER_CHECKS and sc_ctx_check removed, sc_clock_probe and sc_ctx_policy added; round 5: 5
+ * -- sc_ctx_set_pair_policy and sc_ctx_stats added in sc_amd_dev.h). */
+#define SC_ABI_VERSION 5
 int sc_abi_version(void);
 /* device memory helpers for callers that do not bring their own allocator */
 int sc_malloc(sc_ctx* ctx, size_t bytes, void** out_dptr);
@@ -139,7 +140,10 @@ int sc_keyholder_step2_4b(sc_ctx* ctx, int paillier_key, int dgk_key, int l, con
  * given (:153-154) and the shuffle when permutation ([count][l+1] int64, output k takes blinded c at index permutation[b][k]) is
  * given (:516; a row that is not a permutation of 0 .. l acts as the identity), the last three in ONE launch whose store
  * is the shuffle (each item finds its output plane in the permutation row itself: no destination array, no extra launch).  beta: [l][count][nwords] bit-major; rhos / r_rand:
- * [l+1][count][words].  c_unblinded_out (nullable) receives the output of step 4h.  c_out: [l+1][count][nwords]. */
+ * [l+1][count][words].  c_unblinded_out (nullable) receives the output of step 4h.  c_out: [l+1][count][nwords].
+ * FLAG WORDS (here and in sc_initiator_step67): rsmall and delta_a hold 0 or 1 per comparison and only BIT 0 is read -- alpha and
+ * alpha_tilde are bit fields (bit i = the i-th bit of r mod 2^l, of (r - N) mod 2^l), so every flag of a step is taken by position;
+ * a caller's own "true" must be the integer 1 (sc_initiator_step1 and sc_rng_coins produce exactly that). */
 int sc_initiator_step4(sc_ctx* ctx, int dgk_key, int l, const uint32_t* d_enc_dptr, const uint32_t* beta_enc_dptr,
                        const uint64_t* alpha_dptr, const uint64_t* alpha_tilde_dptr, const uint64_t* rsmall_dptr,
                        const uint64_t* delta_a_dptr, const uint32_t* rhos_dptr /* nullable */, int rho_words,

@@ -35,10 +35,22 @@ int sc_ctx_set_chip_share(sc_ctx* ctx, int contexts);
  * a second stream of the context, with its own scratch arena and temporaries, and joined before the recombination.  mode 1
  * (default): automatic -- small batches as described (off when the latency mode is 0, forced on by latency mode 2: tests), and
  * large ones when the context has the chip to itself (chip share 1: launches of 1.5 rounds pack when they overlap); 0: never;
- * 2: always.  A context that shares the chip (sc_ctx_set_chip_share > 1) additionally runs a single-round pair launch -- Alice's
- * rho^N for 32768 items: 2048 waves for 54 ms -- in four segments, so that the other context's short launches do not wait for the
- * whole of it (environment SC_PAIR_SEGMENTS = 1 turns that off; same residues either way). */
+ * 2: always. */
 int sc_ctx_set_fork_mode(sc_ctx* ctx, int mode);
+/* Long pair launches on a shared chip.  The waves of a launch of few rounds retire together, so nothing another context queues
+ * behind it gets a wave slot before a round ends: Alice's rho^N of a shard of 32768 is 2048 waves for 54 ms, and the other shard's
+ * sub-millisecond launches were seen waiting 26 .. 33 ms each behind it.  A context that shares its GPU (sc_ctx_set_chip_share > 1)
+ * therefore cuts such a launch (sc_modexp_shared_sq) into segments -- the same micro-program cut at window boundaries, the pair
+ * parked in the item's table slot in between; same residues.  The decision uses MEASURED quantities only: the time a resident wave
+ * holds its slot = the program's pair squarings and products times the per-op times of the kernel instance, measured on the device
+ * once per process (a lone wave of the caller's operands, ~2 ms); the launch is cut when it would occupy more than half of the
+ * chip's wave slots (by the runtime's occupancy answer) for at most `max_rounds` rounds, into round(hold / hold_ms) segments (at
+ * most 16).  hold_ms: how long a wave may hold its slot, default 5 ms (environment SC_PAIR_HOLD_MS at context creation; 0 or
+ * SC_PAIR_SEGMENTS=1: never cut); max_rounds default 2.5 (longer launches retire their waves a round apart already). */
+int sc_ctx_set_pair_policy(sc_ctx* ctx, double hold_ms, double max_rounds);
+/* Counters of the context since its creation: out[0] = pair launches that ran in segments, out[1] = segments queued for them,
+ * out[2] = op-time calibrations this context performed (the others are zero).  For tests and tools. */
+int sc_ctx_stats(sc_ctx* ctx, uint64_t* out, int n);
 /* The constants behind the automatic policies, measured once per device and process when the first secret key is created (about
  * 80 ms: full, half and one-and-a-half rounds of x^e mod p, 1024 bits, on the two-lane and on the one-lane kernel) instead of fitted
  * on one box: out[0..5] =

@@ -18,11 +18,11 @@ SYMBOLS = [
     "sc_dgk_key_create", "sc_dgk_key_info", "sc_dgk_randomize", "sc_dgk_encrypt_bits_randomized", "sc_dgk_is_zero", "sc_dgk_any_zero",
     "sc_initiator_step1", "sc_keyholder_step2_4b", "sc_initiator_step4", "sc_initiator_step4i", "sc_keyholder_step4j_5", "sc_initiator_step67",
     "sc_rng_seed", "sc_rng_bits", "sc_rng_below", "sc_rng_coins", "sc_rng_permutations",
-    "sc_peak_probe", "sc_mac_counter", "sc_table_traffic_probe", "sc_ctx_set_latency_mode", "sc_ctx_set_onelane_mode", "sc_ctx_set_chip_share", "sc_ctx_set_fork_mode", "sc_ctx_policy", "sc_clock_probe", "sc_comm_unique_id", "sc_comm_init", "sc_allgather", "sc_comm_destroy",
+    "sc_peak_probe", "sc_mac_counter", "sc_table_traffic_probe", "sc_ctx_set_latency_mode", "sc_ctx_set_onelane_mode", "sc_ctx_set_chip_share", "sc_ctx_set_fork_mode", "sc_ctx_set_pair_policy", "sc_ctx_stats", "sc_ctx_policy", "sc_clock_probe", "sc_comm_unique_id", "sc_comm_init", "sc_allgather", "sc_comm_destroy",
 ]
 
 
-ABI_VERSION = 4   # SC_ABI_VERSION of include/sc_amd.h
+ABI_VERSION = 5   # SC_ABI_VERSION of include/sc_amd.h
 
 
 class ScError(RuntimeError):
@@ -112,6 +112,8 @@ def load() -> C.CDLL:
         "sc_ctx_set_onelane_mode": (i32, [vp, i32]),
         "sc_ctx_set_chip_share": (i32, [vp, i32]),
         "sc_ctx_set_fork_mode": (i32, [vp, i32]),
+        "sc_ctx_set_pair_policy": (i32, [vp, C.c_double, C.c_double]),
+        "sc_ctx_stats": (i32, [vp, C.POINTER(C.c_uint64), i32]),
         "sc_ctx_policy": (i32, [vp, C.POINTER(C.c_double)]),
         "sc_clock_probe": (i32, [vp, i32, vp, u64, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "sc_comm_unique_id": (i32, [vp, vp]),

@@ -18,6 +18,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../../include/sc_amd_dev.h"
@@ -165,6 +166,7 @@ struct Prog {
   double redcs_per_item = 0;  // reduction-only passes per item
   double sqrs_per_item = 0;   // squarings (a*a part costs L(L+1)/2 per block instead of L^2)
   std::shared_ptr<std::vector<VmOp>> host_ops;   // the micro-ops on the host (pair programs: cut into segments on demand)
+  uint32_t pair_sqrs = 0, pair_muls = 0;         // pair programs: pair squarings / pair products per item (the hold-time model)
 };
 
 }  // namespace
@@ -194,6 +196,10 @@ struct sc_ctx {
   int latency_mode = 1;                                     // sc_ctx_set_latency_mode: 0 never, 1 automatic, 2 whenever available
   int onelane_mode = 1;                                     // sc_ctx_set_onelane_mode: 0 never, 1 automatic, 2 whenever available
   bool slot_per_item = false;                               // pair launches: a table slot per item instead of per resident wave (segments)
+  // Segment policy of long pair launches on a shared chip (sc_modexp_shared_sq, sc_ctx_set_pair_policy): a resident wave should not
+  // hold its slot for much longer than pair_hold_ms; launches of more than pair_max_rounds rounds are left whole
+  double pair_hold_ms = 5.0, pair_max_rounds = 2.5;
+  uint64_t stat_segmented_launches = 0, stat_segments = 0, stat_pair_calibrations = 0;   // sc_ctx_stats
   int chip_share = 1;                                       // sc_ctx_set_chip_share: contexts working on this GPU at the same time
   void* comm = nullptr;                                     // RCCL communicator of this rank (sc_comm_init), one context per GPU
   int comm_rank = 0, comm_nranks = 0;
@@ -240,6 +246,10 @@ int launch_vm_part2(sc_ctx* ctx, int G, int L, int W, bool neg1, const sc::VmArg
 int launch_pvm_part0(sc_ctx* ctx, int G, int L, bool neg1, bool stamp, const sc::VmArgs& a);
 int launch_pvm_part1(sc_ctx* ctx, int G, int L, bool neg1, bool stamp, const sc::VmArgs& a);
 int launch_pvm_part2(sc_ctx* ctx, int G, int L, bool neg1, bool stamp, const sc::VmArgs& a);
+// resident waves per CU of that pair kernel instance (occupancy query, cached in the context); <= 0 when the instance lives elsewhere
+int pvm_occupancy_part0(sc_ctx* ctx, int G, int L, bool neg1);
+int pvm_occupancy_part1(sc_ctx* ctx, int G, int L, bool neg1);
+int pvm_occupancy_part2(sc_ctx* ctx, int G, int L, bool neg1);
 // sc_launch_misc.hip: 0 on success, a negative number when the launch itself failed
 int launch_xgcd(hipStream_t stream, const uint32_t* x, uint32_t* out, const uint32_t* d_n, int nw, uint64_t count, int* d_status);
 int launch_plain_alice(hipStream_t stream, const uint32_t* r, const uint32_t* nmod, const uint32_t* halfn, int nw, int l, uint64_t count, uint32_t* m1,

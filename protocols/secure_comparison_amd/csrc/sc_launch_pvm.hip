@@ -11,19 +11,22 @@ using namespace sc;
 namespace {
 
 template <int G, int L, int WB = 29, bool NEG1 = false, bool STAMP = false>
-int launch_pvm_cfg(sc_ctx* ctx, const VmArgs& a) {
-  constexpr int NG = 64 / G;
+int pvm_occupancy(sc_ctx* ctx) {
   const int key = 1000 + 100 * L + G + (NEG1 ? 100000 : 0) + (STAMP ? 200000 : 0);
   auto it = ctx->occ_cache.find(key);
-  int occ;
-  if (it == ctx->occ_cache.end()) {
-    int nb = 0;
-    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_pvm<G, L, WB, NEG1, STAMP>), 64, 0));
-    occ = std::max(1, std::min(nb, 16));
-    ctx->occ_cache[key] = occ;
-  } else {
-    occ = it->second;
-  }
+  if (it != ctx->occ_cache.end()) return it->second;
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_pvm<G, L, WB, NEG1, STAMP>), 64, 0) != hipSuccess) return 0;
+  const int occ = std::max(1, std::min(nb, 16));
+  ctx->occ_cache[key] = occ;
+  return occ;
+}
+
+template <int G, int L, int WB = 29, bool NEG1 = false, bool STAMP = false>
+int launch_pvm_cfg(sc_ctx* ctx, const VmArgs& a) {
+  constexpr int NG = 64 / G;
+  const int occ = pvm_occupancy<G, L, WB, NEG1, STAMP>(ctx);
+  if (occ <= 0) return sc_host::fail(ctx, SC_ERR_HIP, "occupancy query failed for k_pvm<%d,%d>", G, L);
   uint64_t need = (a.count + NG - 1) / NG;
   // slot_per_item (segmented launches of more than one round): one wave and one table slot per group of items, so that what a
   // segment parks in the slot's table is still there for the next one; otherwise a grid-stride loop of the resident waves
@@ -55,4 +58,21 @@ int sc_host::SC_CAT(launch_pvm_part, SC_PART)(sc_ctx* ctx, int G, int L, bool ne
 #endif
   (void)ctx; (void)a; (void)stamp;
   return SC_ERR_UNSUPPORTED;
+}
+
+#undef SC_CASE
+#undef SC_CASE_NEG1
+#define SC_CASE(GG, LL) if (G == GG && L == LL && !neg1) return pvm_occupancy<GG, LL>(ctx);
+#define SC_CASE_NEG1(GG, LL) if (G == GG && L == LL && neg1) return pvm_occupancy<GG, LL, 29, true>(ctx);
+
+int sc_host::SC_CAT(pvm_occupancy_part, SC_PART)(sc_ctx* ctx, int G, int L, bool neg1) {
+#if SC_PART == 0
+  SC_CASE_NEG1(4, 18) SC_CASE(4, 18) SC_CASE(2, 18) SC_CASE(1, 18)
+#elif SC_PART == 1
+  SC_CASE(8, 18) SC_CASE(16, 18) SC_CASE(2, 9) SC_CASE(4, 9) SC_CASE(8, 9) SC_CASE(4, 5) SC_CASE(8, 5) SC_CASE(16, 5)
+#else
+  SC_CASE_NEG1(4, 14) SC_CASE(4, 14) SC_CASE_NEG1(8, 14) SC_CASE(8, 14)
+#endif
+  (void)ctx;
+  return -1;
 }

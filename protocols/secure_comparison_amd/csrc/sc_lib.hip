@@ -317,6 +317,21 @@ int run_vm(sc_ctx* ctx, int mod, const Prog& p, const VmExt* exts, int next, uin
   return rc;
 }
 
+// which instance of the pair kernel a launch of `count` items of modulus m takes
+void pvm_instance(const sc_ctx* ctx, const Mod& m, uint64_t count, int* G, int* L, bool* neg1) {
+  *G = m.G; *L = m.L;
+  if (use_latency_config(ctx, m, count) && (m.G == 1 || m.G == 2 || m.G == 4)) { *G = 2 * m.G; *L = 9; }   // (2,9): the 512-bit primes of 1024-bit keys (BASELINE configs[0])
+  // n = -1 (mod 2^29): the instances without the quotient multiply exist for (4,18), (4,14), (8,14)
+  *neg1 = m.n0inv == 1 && ((*G == 4 && *L == 18) || (*L == 14 && (*G == 4 || *G == 8)));
+}
+// resident waves per CU of that instance (the runtime's occupancy answer, not a compiled-in assumption)
+int pvm_occupancy(sc_ctx* ctx, int G, int L, bool neg1) {
+  int occ = pvm_occupancy_part0(ctx, G, L, neg1);
+  if (occ < 0) occ = pvm_occupancy_part1(ctx, G, L, neg1);
+  if (occ < 0) occ = pvm_occupancy_part2(ctx, G, L, neg1);
+  return occ;
+}
+
 // pair programs: nscratch counts limb-form entries (2 per pair entry); macs = multiply-adds per item
 int run_pvm(sc_ctx* ctx, int mod, const Prog& p, const VmExt* exts, int next, uint64_t count) {
   if (count == 0) return SC_OK;
@@ -329,12 +344,9 @@ int run_pvm(sc_ctx* ctx, int mod, const Prog& p, const VmExt* exts, int next, ui
   for (int i = 0; i < next; i++) a.ext[i] = exts[i];
   ctx->mac_counter += (double)count * p.muls_per_item;   // pair programs carry their exact multiply-add count here
   if (!pair_capable(m.G, m.L, m.W)) return fail(ctx, SC_ERR_UNSUPPORTED, "no pair kernel for G=%d L=%d", m.G, m.L);
-  int G = m.G, L = m.L;
-  if (use_latency_config(ctx, m, count) && (m.G == 1 || m.G == 2 || m.G == 4)) { G = 2 * m.G; L = 9; }   // (2,9): the 512-bit primes of 1024-bit keys (BASELINE configs[0])
-  // n = -1 (mod 2^29): the instances without the quotient multiply exist for (4,18), (4,14), (8,14); the stamping twin of (4,18,neg1) is
-  // sc_clock_probe's diagnostic launch
-  const bool neg1 = m.n0inv == 1 && ((G == 4 && L == 18) || (L == 14 && (G == 4 || G == 8)));
-  const bool stamp = neg1 && G == 4 && L == 18 && ctx->stamps != nullptr;
+  int G, L; bool neg1;
+  pvm_instance(ctx, m, count, &G, &L, &neg1);
+  const bool stamp = neg1 && G == 4 && L == 18 && ctx->stamps != nullptr;     // the stamping twin of (4,18,neg1) is sc_clock_probe's diagnostic launch
   int rc = launch_pvm_part0(ctx, G, L, neg1, stamp, a);
   if (rc == SC_ERR_UNSUPPORTED) rc = launch_pvm_part1(ctx, G, L, neg1, stamp, a);
   if (rc == SC_ERR_UNSUPPORTED) rc = launch_pvm_part2(ctx, G, L, neg1, stamp, a);
@@ -417,6 +429,10 @@ int sc_ctx_create(int device_id, sc_ctx** out_ctx) {
   if (hipSetDevice(device_id) != hipSuccess) return SC_ERR_HIP;
   sc_ctx* c = new sc_ctx();
   c->device = device_id;
+  // developer switches, read per context: SC_PAIR_HOLD_MS (target hold time of a resident wave of a long pair launch on a shared chip;
+  // 0 = never cut such launches), SC_PAIR_SEGMENTS=1 (the same "never", kept from round 4)
+  if (const char* e = getenv("SC_PAIR_HOLD_MS")) c->pair_hold_ms = std::max(0.0, atof(e));
+  if (const char* e = getenv("SC_PAIR_SEGMENTS")) if (atoi(e) == 1) c->pair_hold_ms = 0.0;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->num_cu = prop.multiProcessorCount;
   *out_ctx = c;
@@ -1359,11 +1375,15 @@ static int onelane_calibrate(sc_ctx* ctx, OneLaneCal* out) {
   rc = sc_exp_create(ctx, e.data(), (int)e.size(), &exp); if (rc) return rc;
   const uint64_t n1 = (uint64_t)c.simds * 2 * 64, n2 = n1 / 2;                    // numbers of a full one-lane / two-lane round
   uint32_t *x = nullptr, *y = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  struct Cleanup {       // every exit path frees the operands and the events
+    uint32_t **x, **y; hipEvent_t *e0, *e1;
+    ~Cleanup() { if (*x) (void)hipFree(*x); if (*y) (void)hipFree(*y); if (*e0) (void)hipEventDestroy(*e0); if (*e1) (void)hipEventDestroy(*e1); }
+  } cleanup{&x, &y, &e0, &e1};
   HIPCHK(ctx, hipMalloc((void**)&x, n1 * nw * 4));
   HIPCHK(ctx, hipMalloc((void**)&y, n1 * nw * 4));
   HIPCHK(ctx, hipMemsetAsync(x, 0x5a, n1 * nw * 4, ctx->stream));
-  hipEvent_t e0 = nullptr, e1 = nullptr;
   HIPCHK(ctx, hipEventCreate(&e0)); HIPCHK(ctx, hipEventCreate(&e1));
   const int saved_lat = ctx->latency_mode, saved_one = ctx->onelane_mode, saved_share = ctx->chip_share;
   const double saved_macs = ctx->mac_counter;
@@ -1391,10 +1411,17 @@ static int onelane_calibrate(sc_ctx* ctx, OneLaneCal* out) {
   if (!rc) rc = timed(0, n2 / 2, &c.two_only_half);
   if (!rc) rc = timed(0, n2 + n2 / 2, &two_15);
   ctx->latency_mode = saved_lat; ctx->onelane_mode = saved_one; ctx->chip_share = saved_share; ctx->mac_counter = saved_macs;
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(x); (void)hipFree(y);
   if (rc) return rc;
   c.two_half = std::max(0.0, two_15 - c.two_full);
-  c.ok = c.one_full > 0 && c.two_full > 0;
+  // A calibration taken while something else used the chip (another context's launches, another process) gives ratios no idle
+  // chip produces; the policy then keeps the built-in constants rather than rank the forms by a skewed measurement (results are
+  // the same residues either way: only throughput depends on it).  Plausible: a half round costs between a third of and a whole
+  // full round; a two-lane round -- half the numbers -- between 0.3 and 0.9 of a one-lane round.
+  const double r_half = c.one_half / c.one_full, r_two = c.two_full / c.one_full, r_only = c.two_only_half / c.two_full;
+  c.ok = c.one_full > 0 && c.two_full > 0 && r_half > 0.33 && r_half <= 1.0 && r_two > 0.3 && r_two < 0.9 && r_only > 0.3 && r_only <= 1.05 &&
+         c.two_half <= c.two_full * 1.05;
+  if (!c.ok) { OneLaneCal d; d.simds = c.simds; const double scale = c.one_full > 0 ? c.one_full : 1.0;
+               d.one_full *= scale; d.one_half *= scale; d.two_full *= scale; d.two_half *= scale; d.two_only_half *= scale; c = d; }
   *out = c;
   return SC_OK;
 }
@@ -1448,6 +1475,90 @@ static int onelane_for(sc_ctx* ctx, int mod, uint64_t count) {
   if (create_mod(ctx, n.data(), (int)n.size(), false, &twin, &kOneLane) != SC_OK) twin = -1;
   ctx->onelane_twins[mod] = twin;
   return twin < 0 ? mod : twin;
+}
+
+// ---- measured op times of the pair kernel instances (the segment policy of sc_modexp_shared_sq) -------------------------------------
+// One pair squaring and one pair product of ONE resident wave of the instance a launch takes, in milliseconds: timed as the difference
+// of two short programs (16 / 48 squarings; 8 / 24 products) on a single wave of the caller's own operands, best of three (other
+// contexts may be using the chip), once per process, device and instance.  ~2 ms.
+struct PairOpTimes { double sqr_ms = 0, mul_ms = 0; };
+static std::mutex g_pair_cal_mutex;
+static std::map<std::tuple<int, int, int, bool>, PairOpTimes> g_pair_cal;     // (device, G, L, neg1)
+
+static int pair_op_times(sc_ctx* ctx, int mod_m, uint64_t count, const uint32_t* x, int x_words, uint32_t* d_w, uint32_t* d_w1, int wm,
+                         double* sqr_ms, double* mul_ms) {
+  int G, L; bool neg1;
+  pvm_instance(ctx, ctx->mods[mod_m], count, &G, &L, &neg1);
+  const auto key = std::make_tuple(ctx->device, G, L, neg1);
+  std::lock_guard<std::mutex> lock(g_pair_cal_mutex);
+  auto it = g_pair_cal.find(key);
+  if (it != g_pair_cal.end()) { *sqr_ms = it->second.sqr_ms; *mul_ms = it->second.mul_ms; return SC_OK; }
+  const Mod m = ctx->mods[mod_m];
+  const uint32_t nw = (uint32_t)std::min(x_words, m.nwords);
+  auto build = [&](int nsq, int nmul, Prog* out) -> int {
+    std::vector<VmOp> ops;
+    ops.push_back(VmOp{PV_LOADU, 0, 0, nw});
+    ops.push_back(VmOp{PV_MULC, 2, 0, 0});
+    ops.push_back(VmOp{PV_STT, 1, 0, 0});
+    for (int i = 0; i < nsq; i++) ops.push_back(VmOp{PV_SQR, 0, 0, 0});
+    for (int i = 0; i < nmul; i++) ops.push_back(VmOp{PV_MULT, 1, 0, 0});
+    ops.push_back(VmOp{PV_OUT, 1, 2, 0});
+    ops.push_back(VmOp{PV_END, 0, 0, 0});
+    Prog p;
+    p.nops = (uint32_t)ops.size(); p.nscratch = 4 + (m.G == 1 ? 1 : 0); p.nconst = 4;
+    int rc = upload(ctx, ops.data(), ops.size() * sizeof(VmOp), (void**)&p.d_ops); if (rc) return rc;
+    rc = get_pair_consts(ctx, mod_m, &p.d_consts); if (rc) return rc;
+    *out = p;
+    return SC_OK;
+  };
+  Prog progs[4];
+  const int shapes[4][2] = {{16, 0}, {48, 0}, {0, 8}, {0, 24}};
+  for (int i = 0; i < 4; i++) { int rc = build(shapes[i][0], shapes[i][1], &progs[i]); if (rc) return rc; }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipEventCreate(&e0));
+  if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return fail(ctx, SC_ERR_HIP, "pair_op_times: no event"); }
+  const int saved_lat = ctx->latency_mode;
+  const double saved_macs = ctx->mac_counter;
+  // the wave must run on the SAME instance as the launch it stands for: the batch-size policy is told the real batch size by keeping
+  // the latency mode out of it (a tiny batch would otherwise pick the small-batch twin)
+  ctx->latency_mode = use_latency_config(ctx, m, count) ? 2 : 0;
+  const uint64_t one_wave = std::min<uint64_t>(count, (uint64_t)(64 / G));
+  VmExt ex3[3] = {mk_ext(x, x_words, x_words), mk_ext(d_w, wm, wm), mk_ext(d_w1, wm, wm)};
+  double ms[4] = {1e30, 1e30, 1e30, 1e30};
+  int rc = SC_OK;
+  for (int rep = 0; rep < 4 && !rc; rep++)          // the first pass loads the code
+    for (int i = 0; i < 4 && !rc; i++) {
+      if (hipEventRecord(e0, ctx->stream) != hipSuccess) { rc = fail(ctx, SC_ERR_HIP, "pair_op_times: event"); break; }
+      rc = run_pvm(ctx, mod_m, progs[i], ex3, 3, one_wave);
+      if (!rc && (hipEventRecord(e1, ctx->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess)) rc = fail(ctx, SC_ERR_HIP, "pair_op_times: launch failed");
+      float t = 0;
+      if (!rc && hipEventElapsedTime(&t, e0, e1) == hipSuccess && rep > 0 && t < ms[i]) ms[i] = t;
+    }
+  ctx->latency_mode = saved_lat; ctx->mac_counter = saved_macs;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (rc) return rc;
+  PairOpTimes t;
+  t.sqr_ms = std::max(1e-6, (ms[1] - ms[0]) / 32.0);
+  t.mul_ms = std::max(1e-6, (ms[3] - ms[2]) / 16.0);
+  g_pair_cal[key] = t;
+  ctx->stat_pair_calibrations++;
+  *sqr_ms = t.sqr_ms; *mul_ms = t.mul_ms;
+  return SC_OK;
+}
+
+int sc_ctx_set_pair_policy(sc_ctx* ctx, double hold_ms, double max_rounds) {
+  if (!ctx || hold_ms < 0 || !(max_rounds > 0)) return SC_ERR_ARG;
+  ctx->pair_hold_ms = hold_ms;
+  ctx->pair_max_rounds = max_rounds;
+  return SC_OK;
+}
+
+int sc_ctx_stats(sc_ctx* ctx, uint64_t* out, int n) {
+  if (!ctx || !out || n < 0) return SC_ERR_ARG;
+  const uint64_t v[3] = {ctx->stat_segmented_launches, ctx->stat_segments, ctx->stat_pair_calibrations};
+  for (int i = 0; i < n; i++) out[i] = i < 3 ? v[i] : 0;
+  return SC_OK;
 }
 
 int sc_ctx_set_chip_share(sc_ctx* ctx, int contexts) {
@@ -1551,6 +1662,10 @@ int sc_modexp_shared_sq(sc_ctx* ctx, int mod_m, int mod_m2, int exp, const uint3
     Prog p;
     if (m.G == 1) nsc += 1;   // one-lane pair products park an intermediate in a spare row (the last one) of the slot's table
     p.nops = (uint32_t)ops.size(); p.nscratch = nsc; p.nconst = 4; p.muls_per_item = macs;
+    for (const VmOp& o : ops) {
+      const uint32_t oc = o.w0 & 0xff;
+      if (oc == PV_SQR) p.pair_sqrs++; else if (oc == PV_MULT || oc == PV_MULC) p.pair_muls++;
+    }
     p.host_ops = std::make_shared<std::vector<VmOp>>(ops);
     int rc = upload(ctx, ops.data(), ops.size() * sizeof(VmOp), (void**)&p.d_ops); if (rc) return rc;
     rc = get_pair_consts(ctx, mod_m, &p.d_consts); if (rc) return rc;
@@ -1565,21 +1680,27 @@ int sc_modexp_shared_sq(sc_ctx* ctx, int mod_m, int mod_m2, int exp, const uint3
     // queues behind such a launch gets a wave slot before it ends: the other shard's short, latency-bound launches (the inversion
     // sweeps of steps 1 and 6 / 7, the assembly launch after ITS pair launch) were seen waiting 26 .. 32 ms each.  With segments
     // they wait for a quarter of that.  Multi-round launches need none of this (their waves retire a round apart).
-    static const int want_segments = []{ const char* e = getenv("SC_PAIR_SEGMENTS"); return e ? atoi(e) : 4; }();
-    const uint64_t wave_items = (count + (uint64_t)(64 / m.G) - 1) / (uint64_t)(64 / m.G);
-    const uint64_t resident = (uint64_t)ctx->num_cu * 4 * SC_PVM_WAVES;
-    // (4,18): Alice's rho^N of a shard, one round.  (2,18): the key holder's y^p mod p^2 of a shard, 3 x 32768 items = 1.5 rounds of
-    // 14 ms -- the short launches that close the other shard's step (recombination, steps 6 / 7) wait behind them at the end of a
-    // step, where nothing hides it: two or three segments, a table slot per item (more than one round)
-    const bool one_round = m.G == 4 && m.L == 18 && wave_items <= resident && wave_items * 2 > resident;
-    const bool few_rounds = m.G == 2 && m.L == 18 && wave_items > resident / 2 && wave_items <= 2 * resident;
-    // The L = 14 pair twins of 1536 / 3072-bit moduli (the per-GPU share of configs[4]: Alice's launch of a shard is two rounds of
-    // 100 ms on k_pvm<8,14>, the key holder's three rounds on k_pvm<4,14>): rounds that long starve the other shard whatever their
-    // number -- 55.7 k -> 56.6 k/s with eight / three segments (for two to three 54-ms rounds of the (4,18) launch at 65536
-    // comparisons per shard the same measured 0.6 % slower: those stay whole)
-    const bool l14_rounds = m.L == 14 && (m.G == 4 || m.G == 8) && wave_items > resident / 2 && wave_items <= 3 * resident;
-    const bool segmented = want_segments > 1 && ctx->chip_share > 1 && !ctx->stamps && ex.bits >= 512 && (one_round || few_rounds || l14_rounds);
-    const int K = one_round ? want_segments : (l14_rounds && m.G == 8 ? 2 * want_segments : std::max(2, want_segments - 1));
+    // Whether, and into how many segments: from MEASUREMENTS, not from the shape of the launch.  A resident wave holds its slot for
+    // hold = (pair squarings x t_sqr + pair products x t_mul) of this program, with the two op times of this kernel instance measured on
+    // the device (pair_op_times, once per process and instance: a lone wave, like each of two waves sharing a SIMD, issues one
+    // multiply-add per ~9.5 cycles, so its time through the program is the time a round of resident waves takes).  The launch is cut when
+    // it would take more than half of the chip's wave slots for that long on a SHARED chip (sc_ctx_set_chip_share), into
+    // round(hold / pair_hold_ms) segments; launches of more than pair_max_rounds rounds stay whole (their waves retire a round apart
+    // anyway, and every segment boundary costs a drain of the chip).  Both knobs: sc_ctx_set_pair_policy.
+    int iG, iL; bool ineg1;
+    pvm_instance(ctx, m, count, &iG, &iL, &ineg1);
+    const int occ = pvm_occupancy(ctx, iG, iL, ineg1);
+    const uint64_t wave_items = (count + (uint64_t)(64 / iG) - 1) / (uint64_t)(64 / iG);
+    const uint64_t resident = (uint64_t)ctx->num_cu * (uint64_t)std::max(1, occ);
+    const double rounds = (double)wave_items / (double)resident;
+    int K = 1;
+    if (ctx->pair_hold_ms > 0 && ctx->chip_share > 1 && !ctx->stamps && occ > 0 && wave_items * 2 > resident && rounds <= ctx->pair_max_rounds) {
+      double t_sqr = 0, t_mul = 0;
+      int rcc = pair_op_times(ctx, mod_m, count, x, x_words, d_w, d_w1, wm, &t_sqr, &t_mul); if (rcc) return rcc;
+      const double hold_ms = it1->second.pair_sqrs * t_sqr + it1->second.pair_muls * t_mul;
+      K = (int)std::min(16.0, std::max(1.0, std::floor(hold_ms / ctx->pair_hold_ms + 0.5)));
+    }
+    const bool segmented = K > 1;
     if (!segmented) {
       int rc = run_pvm(ctx, mod_m, it1->second, ex3, 3, count); if (rc) return rc;
     } else {
@@ -1620,8 +1741,8 @@ int sc_modexp_shared_sq(sc_ctx* ctx, int mod_m, int mod_m2, int exp, const uint3
         }
         its = ctx->seg_progs.emplace(ks, segs).first;
       }
-      ctx->slot_per_item = true;        // (one round: the ordinary grid already is one wave per group of items -- unless the kernel's
-                                        // occupancy on this part were lower than assumed above: asked for explicitly, never relied on)
+      ctx->slot_per_item = true;        // a table slot per item: what a segment parks is still there for the next one, whatever the rounds
+      ctx->stat_segmented_launches++; ctx->stat_segments += its->second.size();
       int rcs = SC_OK;
       for (const Prog& sp : its->second) { rcs = run_pvm(ctx, mod_m, sp, ex3, 3, count); if (rcs) break; }
       ctx->slot_per_item = false;

@@ -63,6 +63,33 @@ class DgkKey:
     secret: bool
 
 
+_HW_QUEUES_WARNED = False
+
+
+def _default_hw_queues() -> None:
+    """The HIP runtime multiplexes a process's streams onto 4 hardware queues by default, and streams that land on one queue run in
+    sequence.  Two library contexts with their fork streams are four streams already (configs[1]: 114 k/s with a queue each, 80 k/s
+    when a fifth stream of the same process made two of them share one); byte-transport sessions add copy streams, background
+    randomizers another context.  The runtime reads GPU_MAX_HW_QUEUES when it initialises, i.e. at the first GPU call of the process:
+    the FIRST ENGINE of a process asks for 32 -- unless the operator exported a value (it wins), and with a warning when the runtime is
+    up already and the default of 4 is what it got (round 4 set the variable when the package was imported: a library changing its
+    host's runtime configuration at import)."""
+    global _HW_QUEUES_WARNED
+    import os
+    import warnings
+
+    if "GPU_MAX_HW_QUEUES" in os.environ:
+        return
+    if torch.cuda.is_initialized():
+        if not _HW_QUEUES_WARNED:
+            _HW_QUEUES_WARNED = True
+            warnings.warn("the HIP runtime was initialised before the first secure-comparison engine and GPU_MAX_HW_QUEUES is not set: streams of "
+                          "concurrent contexts may share the runtime's 4 default hardware queues and run in sequence (export GPU_MAX_HW_QUEUES=32 "
+                          "before the process's first GPU call)", RuntimeWarning, stacklevel=3)
+        return
+    os.environ["GPU_MAX_HW_QUEUES"] = "32"
+
+
 class Engine:
     """One library context (sc_ctx): one per process and device, or one per concurrent shard / session thread of a device.
     Tensors are int32 views of uint32 words, shape [count, nwords].  An engine belongs to ONE host thread at a time: it orders its
@@ -71,6 +98,7 @@ class Engine:
 
     def __init__(self, device: int | None = None) -> None:
         self.lib = _lib.load()
+        _default_hw_queues()
         if not torch.cuda.is_available():
             raise ScError("no GPU visible: the secure-comparison engine has no CPU fallback")
         self.device_index = torch.cuda.current_device() if device is None else device
@@ -824,6 +852,17 @@ class Engine:
     def set_fork_mode(self, mode: int) -> None:
         """Fork / join of the CRT's q-side inside one call on small batches (sc_ctx_set_fork_mode): 0 never, 1 automatic (default)."""
         self._check(self.lib.sc_ctx_set_fork_mode(self.ctx, int(mode)))
+
+    def set_pair_policy(self, hold_ms: float = 5.0, max_rounds: float = 2.5) -> None:
+        """Segments of long pair launches on a shared chip (sc_ctx_set_pair_policy): a resident wave holds its slot for about `hold_ms`
+        (0: never cut); launches of more than `max_rounds` rounds stay whole."""
+        self._check(self.lib.sc_ctx_set_pair_policy(self.ctx, float(hold_ms), float(max_rounds)))
+
+    def stats(self) -> dict:
+        """Counters of the context (sc_ctx_stats)."""
+        v = (C.c_uint64 * 3)()
+        self._check(self.lib.sc_ctx_stats(self.ctx, v, 3))
+        return {"segmented_pair_launches": int(v[0]), "pair_segments": int(v[1]), "pair_calibrations": int(v[2])}
 
     def set_chip_share(self, contexts: int) -> None:
         """This engine shares its GPU with contexts - 1 other engines working at the same time (sc_ctx_set_chip_share)."""

@@ -133,7 +133,7 @@ def spawn_ranks(script: str, argv: Sequence[str], nranks: int, *, need_gpus: boo
             env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks), MASTER_ADDR="127.0.0.1",
                        MASTER_PORT=str(port), SC_AMD_RENDEZVOUS_TIMEOUT_S=str(RENDEZVOUS_TIMEOUT_S))
             env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            env.setdefault("GPU_MAX_HW_QUEUES", "32")         # a hardware queue per stream of the rank (package __init__)
+            env.setdefault("GPU_MAX_HW_QUEUES", "32")         # a hardware queue per stream of the rank (engine.py::_default_hw_queues)
             if extra_env:
                 env.update(extra_env)
             log = os.path.join(tmp.name, f"rank{r}.stderr")

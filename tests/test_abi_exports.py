@@ -27,11 +27,11 @@ def test_library_builds_loads_and_exports_everything():
     for name in names:
         assert hasattr(lib, name), f"{name} declared in include/ but not exported"
     assert sorted(_lib.SYMBOLS) == names          # the ctypes binding covers both headers
-    assert _lib.load().sc_abi_version() == _lib.ABI_VERSION == 4
+    assert _lib.load().sc_abi_version() == _lib.ABI_VERSION == 5
     # what a maintainer binds (sc_amd.h) holds no primitive, policy switch or probe: those are sc_amd_dev.h's
     public = declared_symbols(("sc_amd.h",))
     assert not [n for n in public if n.startswith(("sc_mod", "sc_exp_", "sc_const_", "sc_fbt_", "sc_ctx_set_latency", "sc_ctx_set_onelane",
-                                                   "sc_ctx_set_chip", "sc_ctx_set_fork", "sc_peak", "sc_mac", "sc_table", "sc_clock", "sc_crt", "sc_plain"))]
+                                                   "sc_ctx_set_chip", "sc_ctx_set_fork", "sc_ctx_set_pair", "sc_ctx_stats", "sc_peak", "sc_mac", "sc_table", "sc_clock", "sc_crt", "sc_plain"))]
     assert {"sc_initiator_step1", "sc_keyholder_step2_4b", "sc_initiator_step4", "sc_keyholder_step4j_5", "sc_initiator_step67",
             "sc_paillier_randomize", "sc_paillier_decrypt", "sc_dgk_randomize", "sc_dgk_any_zero", "sc_rng_below", "sc_allgather"} <= set(public)
 

@@ -32,12 +32,18 @@ def test_segmented_pair_launches_of_3072_bit_keys(engine, keys):
     try:
         for scheme, count in ((alice_p, 12000), (bob_p, 24000)):       # ragged on purpose: the last wave of either launch is partly filled
             rho = engine.upload(base, scheme.mod_n.nwords).repeat(count // len(base), 1).contiguous()
+            before = engine.stats()
             whole = scheme.randomizer_batch(rho)
+            assert engine.stats()["segmented_pair_launches"] == before["segmented_pair_launches"]      # a context that owns the chip cuts nothing
             engine.set_chip_share(2)
             try:
                 seg = scheme.randomizer_batch(rho)
             finally:
                 engine.set_chip_share(1)
+            after = engine.stats()
+            cut = after["segmented_pair_launches"] - before["segmented_pair_launches"]
+            assert cut == (2 if scheme is bob_p else 1), after                                          # Alice: one pair launch; the key holder: one per prime
+            assert after["pair_segments"] - before["pair_segments"] >= 3 * cut                            # 100-ms / 33-ms rounds against a 5-ms hold: many segments
             assert torch.equal(whole, seg)
             rows = [0, 1, 7, 48, 49, len(base), rho.shape[0] - 51, rho.shape[0] - 1]
             assert engine.download(seg[torch.tensor(rows, device=seg.device)]) == [pow(base[i % len(base)], sk.n, n2) for i in rows]
@@ -81,3 +87,40 @@ def test_concurrent_sessions_are_coalesced_into_batch_launches(engine, keys, pbi
     for side in ("alice", "bob"):
         assert stats[side]["largest"] == sessions and stats[side]["fallbacks"] == 0
     assert stats["alice"]["calls"] == 3 and stats["bob"]["calls"] == 3      # step 1 / 4 / 6+7; the randomizers ahead of time / steps 2-4b / 4j+5
+
+
+def test_pair_segment_policy_follows_the_measured_hold_time(engine, keys):
+    """sc_ctx_set_pair_policy: the number of segments of a long pair launch on a shared chip is round(hold / hold_ms) with the hold time
+    MEASURED on the device (per-op times of the kernel instance x the program's op counts) -- no shape literal: halving hold_ms about
+    doubles the segments, hold_ms = 0 and launches longer than max_rounds stay whole, and every form gives the same residues."""
+    from protocols.secure_comparison_amd import Paillier
+
+    sk = oracle_paillier(keys, 2048)
+    alice_p = Paillier(sk.n, engine=engine)
+    rng = random.Random(8)
+    base = [rng.randrange(1, sk.n) for _ in range(64)]
+    rho = engine.upload(base, alice_p.mod_n.nwords).repeat(20480 // 64, 1).contiguous()       # 1280 waves of k_pvm<4,18>: 0.6 of a round
+    engine.set_latency_mode(1)
+    whole = alice_p.randomizer_batch(rho)
+    engine.set_chip_share(2)
+    counts = {}
+    try:
+        for hold in (0.0, 20.0, 10.0, 5.0):
+            engine.set_pair_policy(hold, 2.5)
+            b = engine.stats()
+            got = alice_p.randomizer_batch(rho)
+            a = engine.stats()
+            counts[hold] = (a["segmented_pair_launches"] - b["segmented_pair_launches"], a["pair_segments"] - b["pair_segments"])
+            assert torch.equal(got, whole), hold
+        engine.set_pair_policy(5.0, 0.5)                       # 0.6 rounds > max_rounds: left whole
+        b = engine.stats()
+        assert torch.equal(alice_p.randomizer_batch(rho), whole) and engine.stats()["segmented_pair_launches"] == b["segmented_pair_launches"]
+    finally:
+        engine.set_pair_policy(5.0, 2.5)
+        engine.set_chip_share(1)
+        engine.set_latency_mode(0)
+    assert counts[0.0] == (0, 0)
+    segs = {h: c[1] for h, c in counts.items() if h > 0}
+    assert all(counts[h][0] == 1 for h in segs) and 2 <= segs[20.0] < segs[10.0] < segs[5.0] <= 16, counts
+    assert 1.5 <= segs[10.0] / segs[20.0] <= 2.6 and 1.5 <= segs[5.0] / segs[10.0] <= 2.6, counts     # the hold time is ~50 ms: 2-3, 5, 10-11 segments
+    assert engine.download(whole[:2]) == [pow(v, sk.n, sk.n * sk.n) for v in base[:2]]
