@@ -1478,9 +1478,10 @@ static int onelane_for(sc_ctx* ctx, int mod, uint64_t count) {
 }
 
 // ---- measured op times of the pair kernel instances (the segment policy of sc_modexp_shared_sq) -------------------------------------
-// One pair squaring and one pair product of ONE resident wave of the instance a launch takes, in milliseconds: timed as the difference
-// of two short programs (16 / 48 squarings; 8 / 24 products) on a single wave of the caller's own operands, best of three (other
-// contexts may be using the chip), once per process, device and instance.  ~2 ms.
+// One pair squaring and one pair product of a resident wave of the instance a launch takes, in milliseconds, with the chip as full as the
+// launch itself makes it (up to one round of resident waves: two waves share a SIMD's issue slots, a lone wave runs its program almost
+// twice as fast): timed as the difference of two short programs (16 / 48 squarings; 8 / 24 products) on the caller's own operands, best
+// of three (other contexts may be using the chip), once per process, device and instance.  A few milliseconds.
 struct PairOpTimes { double sqr_ms = 0, mul_ms = 0; };
 static std::mutex g_pair_cal_mutex;
 static std::map<std::tuple<int, int, int, bool>, PairOpTimes> g_pair_cal;     // (device, G, L, neg1)
@@ -1523,7 +1524,8 @@ static int pair_op_times(sc_ctx* ctx, int mod_m, uint64_t count, const uint32_t*
   // the wave must run on the SAME instance as the launch it stands for: the batch-size policy is told the real batch size by keeping
   // the latency mode out of it (a tiny batch would otherwise pick the small-batch twin)
   ctx->latency_mode = use_latency_config(ctx, m, count) ? 2 : 0;
-  const uint64_t one_wave = std::min<uint64_t>(count, (uint64_t)(64 / G));
+  const int occ = pvm_occupancy(ctx, G, L, neg1);
+  const uint64_t one_wave = std::min<uint64_t>(count, (uint64_t)(64 / G) * (uint64_t)ctx->num_cu * (uint64_t)std::max(1, occ));   // (at most one round)
   VmExt ex3[3] = {mk_ext(x, x_words, x_words), mk_ext(d_w, wm, wm), mk_ext(d_w1, wm, wm)};
   double ms[4] = {1e30, 1e30, 1e30, 1e30};
   int rc = SC_OK;

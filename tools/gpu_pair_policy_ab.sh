@@ -15,7 +15,7 @@ except Exception as e:
 PY
 }
 for rep in 1 2; do
-  for hold in 0 13 5 3; do
+  for hold in 0 13 7 5; do
     SC_PAIR_HOLD_MS=$hold python bench.py --steps 10 --warmup 2 --no-extras --no-other-configs --no-cpu-baseline > /tmp/ab.json 2> /tmp/ab.err || tail -3 /tmp/ab.err >> $out
     echo "B=65536  hold_ms=$hold  $(line /tmp/ab.json)" >> $out
   done
