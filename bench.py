@@ -969,7 +969,7 @@ def measure(args, torch, dist, rank: int, world: int, full: bool, rt=None):
         abytes = algorithmic_bytes_per_comparison(l, args.pbits, dbits, args.rbits)
         # HBM traffic of the dominant launch from the committed PMC pass (rocprofv3 cannot run inside this process)
         traffic = None
-        for name in ("r04_dominant_kernel_traffic.json", "r03_dominant_kernel_traffic.json", "r02_dominant_kernel_traffic.json", "r01_dominant_kernel_traffic.json"):
+        for name in ("r05_dominant_kernel_traffic.json", "r04_dominant_kernel_traffic.json", "r03_dominant_kernel_traffic.json", "r02_dominant_kernel_traffic.json", "r01_dominant_kernel_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tpath) and B == 65536 and args.pbits == 2048 and l == 32 and use_crt:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
