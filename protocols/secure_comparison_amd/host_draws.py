@@ -64,16 +64,34 @@ class HostDraws:
                 return v
 
     def bits_rows(self, bits: int, count: int) -> np.ndarray:
-        """`count` uniform integers below 2^bits as rows [count][ceil(bits/32)] (the DGK randomizer exponents)."""
-        nw = (bits + 31) // 32
-        rows = np.frombuffer(self.take(4 * nw * count), dtype="<u4").reshape(count, nw).copy()
-        top = bits - 32 * (nw - 1)
-        if top < 32:
-            rows[:, -1] &= np.uint32((1 << top) - 1)
-        return rows
+        """`count` uniform integers below 2^bits as rows [count][ceil(bits/32)] (the DGK randomizer exponents); pooled like
+        below_rows_nonzero (the rows handed out are views of the pool: read them, do not write them)."""
+        pools = self.__dict__.setdefault("_bits_pools", {})
+        rows, at = pools.get(bits, (None, 0))
+        if rows is None or at + count > len(rows):
+            n = max(self.POOL_ROWS, count)
+            nw = (bits + 31) // 32
+            rows, at = np.frombuffer(self.take(4 * nw * n), dtype="<u4").reshape(n, nw).copy(), 0
+            top = bits - 32 * (nw - 1)
+            if top < 32:
+                rows[:, -1] &= np.uint32((1 << top) - 1)
+        pools[bits] = (rows, at + count)
+        return rows[at:at + count]
+
+    POOL_ROWS = 8192          # values / permutations drawn per vectorised refill of a pool
 
     def below_rows_nonzero(self, n: int, count: int) -> np.ndarray:
-        """`count` uniform integers in [1, n) as rows [count][ceil(bitlen(n)/32)], n < 2^127 (step 4i's rho_i = 1 + randbelow(u - 1))."""
+        """`count` uniform integers in [1, n) as rows [count][ceil(bitlen(n)/32)], n < 2^127 (step 4i's rho_i = 1 + randbelow(u - 1)).
+        Independent draws are handed out from a pool that is refilled a few thousand values at a time: the numpy calls of a
+        refill cost the same for 33 values as for 8192, and a session asks for l + 1."""
+        pools = self.__dict__.setdefault("_below_pools", {})
+        rows, at = pools.get(n, (None, 0))
+        if rows is None or at + count > len(rows):
+            rows, at = self._below_rows_nonzero(n, max(self.POOL_ROWS, count)), 0
+        pools[n] = (rows, at + count)
+        return rows[at:at + count]
+
+    def _below_rows_nonzero(self, n: int, count: int) -> np.ndarray:
         m = n - 1                                  # draw v in [0, m), return v + 1
         k = m.bit_length()
         nw = (n.bit_length() + 31) // 32
@@ -108,13 +126,19 @@ class HostDraws:
 
     def permutation(self, k: int) -> list[int]:
         """Uniform permutation of range(k): entry j = the source index of output j (the shuffle of SC/initiator.py:212-226).  Sorting
-        k independent 64-bit keys orders them uniformly; a tie (probability < k^2 / 2^65) is redrawn, so the permutation is exactly
-        uniform."""
-        while True:
-            keys = np.frombuffer(self.take(8 * k), dtype="<u8")
-            order = np.argsort(keys, kind="stable")
-            if k < 2 or bool((np.diff(keys[order]) != 0).all()):
-                return order.tolist()
+        k independent 64-bit keys orders them uniformly; a row with a tie (probability < k^2 / 2^65) is dropped, so every
+        permutation handed out is exactly uniform.  Pooled like below_rows_nonzero."""
+        pools = self.__dict__.setdefault("_perm_pools", {})
+        perms = pools.get(k)
+        if not perms:
+            rows = max(64, self.POOL_ROWS // max(1, k))
+            keys = np.frombuffer(self.take(8 * k * rows), dtype="<u8").reshape(rows, k)
+            order = np.argsort(keys, axis=1, kind="stable")
+            if k > 1:
+                ok = (np.diff(np.take_along_axis(keys, order, axis=1), axis=1) != 0).all(axis=1)
+                order = order[ok]
+            perms = pools[k] = order.tolist()
+        return perms.pop()
 
 
 class SecretsDraws(HostDraws):

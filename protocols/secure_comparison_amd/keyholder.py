@@ -179,11 +179,16 @@ class KeyHolder:
         for b, it in enumerate(items):
             z[b], exps[:, b] = it[0], it[1]
         plain, d, beta = KeyHolder.step_2_4b_batch(e.upload_words(z), l, pai, dgk, e.upload_words(exps))
-        dv, bv = e.download_words(d), e.download_words(beta)
+        # [d] and the planes [beta_i] as ONE host array [l+1][K][nd]: a session's l + 1 ciphertexts are then consecutive rows of one
+        # block, which the initiator's next batched call takes back without converting a single integer (coalesce.rows_of)
+        planes = np.concatenate([e.download_words(d)[None], e.download_words(beta)])
         z1, z2 = e.download_words(plain.zeta_1), e.download_words(plain.zeta_2)
         pub = dgk.for_wire()
-        ds = DGKCiphertext.rows(dv, pub, fresh=True)
-        return [(ds[b], DGKCiphertext.rows(bv[:, b], pub, fresh=True), (z1[b], z2[b])) for b in range(k)]
+        out = []
+        for b in range(k):
+            cts = DGKCiphertext.rows(planes[:, b], pub, fresh=True)
+            out.append((cts[0], cts[1:], (z1[b], z2[b])))
+        return out
 
     def _run_step_4j_5(self, items: list) -> list:
         """Steps 4j, 5 + the three `.randomize()` of K sessions: one sc_keyholder_step4j_5 call (the randomizers finished ahead of
