@@ -16,11 +16,14 @@ with the same draws (tests/test_gpu_round5.py, tests/test_coalesce_cpu.py).
 from __future__ import annotations
 
 import asyncio
+import contextlib
 import gc
 import time
 from typing import Any, Callable, Sequence
 
 import numpy as np
+
+from .limbs import RowBlock
 
 
 class _Queue:
@@ -127,25 +130,70 @@ class StepCoalescer:
 
 
 # ---- word rows: how coalesced sessions hand ciphertext values on without ever making Python integers of them ------------------------
-def rows_of(cts: Sequence, nwords: int) -> np.ndarray:
-    """The values of a list of ciphertexts as an array [len][nwords] of little-endian 32-bit words: the very rows a coalesced peer's
-    batch launch produced when the ciphertexts still refer to consecutive rows of one array (no conversion, no copy), else converted
-    from their integers."""
+def rows_of(cts: Sequence, nwords: int):
+    """The values of a list of ciphertexts as rows of little-endian 32-bit words: the very block a coalesced peer's batch launch
+    produced when the ciphertexts are ALL its rows in order (a limbs.RowBlock or an array: no conversion, no copy), consecutive
+    rows of one array as a slice of it, else an array [len][nwords] converted from their integers."""
     block = cts[0]._block if cts else None
-    if block is not None and block.shape[-1] == nwords:
+    if block is not None:
         at = cts[0]._row
         for c in cts:
             if c._block is not block or c._row != at:
                 break
             at += 1
         else:
-            return block[cts[0]._row:at]
+            if type(block) is RowBlock:
+                if cts[0]._row == 0 and at == len(block) and block.words == nwords:
+                    return block
+            elif block.shape[-1] == nwords:
+                return block[cts[0]._row:at]
     out = np.empty((len(cts), nwords), dtype="<u4")
     for i, c in enumerate(cts):
         out[i] = np.frombuffer(c.peek_value().to_bytes(4 * nwords, "little"), dtype="<u4")
     return out
 
 
+STACK_STATS = {"taken_whole": 0, "assembled": 0}      # how stack_blocks got its arrays (tests, tools)
+
+
+def stack_blocks(blocks: Sequence, rows: int, words: int) -> np.ndarray:
+    """The bit-major array [rows][K][words] with session i's block at [:, i]: the peer's own batch array when the K blocks are that
+    array's K sessions in order (the common case: both players coalesce the same sessions), else assembled block by block."""
+    first = blocks[0]
+    if type(first) is RowBlock and first.b == 0 and first.base.shape == (rows, len(blocks), words):
+        base = first.base
+        for i, blk in enumerate(blocks):
+            if type(blk) is not RowBlock or blk.base is not base or blk.b != i:
+                break
+        else:
+            STACK_STATS["taken_whole"] += 1
+            return base
+    STACK_STATS["assembled"] += 1
+    out = np.empty((rows, len(blocks), words), dtype="<u4")
+    for i, blk in enumerate(blocks):
+        out[:, i] = blk.array() if type(blk) is RowBlock else blk
+    return out
+
+
 def int_rows(values: Sequence[int], nwords: int) -> np.ndarray:
     """Python integers as rows of words."""
     return np.frombuffer(b"".join(v.to_bytes(4 * nwords, "little") for v in values), dtype="<u4").reshape(len(values), nwords)
+
+
+@contextlib.contextmanager
+def quiet_collector(generation0: int = 1_000_000):
+    """For applications that serve bursts of thousands of concurrent sessions: inside this context the cyclic garbage collector's
+    generation-0 threshold is raised (a collection per `generation0` container allocations instead of per 700) and the objects that
+    exist already are frozen out of its passes; both are restored on exit.  A thousand sessions in flight keep ~10^5 small container
+    objects alive (messages of l + 1 ciphertext objects each); CPython's default thresholds then walk them -- and everything torch
+    and numpy imported -- a few hundred times per burst: measured 4.4 k -> 6.8-8.5 k comparisons/s at l = 32 / 2048-bit.  The library
+    never does this by itself (it is a process-wide setting)."""
+    old = gc.get_threshold()
+    gc.collect()
+    gc.freeze()
+    gc.set_threshold(generation0, old[1], old[2])
+    try:
+        yield
+    finally:
+        gc.set_threshold(*old)
+        gc.unfreeze()

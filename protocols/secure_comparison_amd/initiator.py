@@ -240,29 +240,35 @@ class Initiator:
         the l + 1 fresh ciphertexts [c_i] as sent."""
         import numpy as np
 
+        from .coalesce import stack_blocks
+        from .limbs import RowBlock
+
         dgk, l = self.scheme_dgk, self.l_maximum_bit_length
         e, nd, k = dgk.engine, dgk.mod_n.nwords, len(items)
         ew, er = (dgk.public_key.u.bit_length() + 31) // 32, (dgk.randomizer_bits + 31) // 32
-        planes, rhos, exps = (np.empty((l + 1, k, w), dtype="<u4") for w in (nd, ew, er))
+        planes = stack_blocks([it[0] for it in items], l + 1, nd)            # the key holder's own array when the sessions are the same
+        rhos, exps = (np.empty((l + 1, k, w), dtype="<u4") for w in (ew, er))
         for b, it in enumerate(items):
-            planes[:, b], rhos[:, b], exps[:, b] = it[0], it[3], it[5]
+            rhos[:, b], exps[:, b] = it[3], it[5]
         flags = lambda col: e.upload_u64([it[1][col] & 0xFFFFFFFFFFFFFFFF for it in items])   # noqa: E731
         plain = AlicePlain(None, flags(0), flags(1), flags(2), None)
         tp = e.upload_words(planes)
         c, _ = Initiator.step_4_batch(tp[0], tp[1:], plain, e.upload_u64([it[2] for it in items]), dgk, e.upload_words(rhos),
                                       torch.from_numpy(np.array([it[4] for it in items], dtype=np.int64)).to(tp.device), e.upload_words(exps))
         cv, pub = e.download_words(c), dgk.for_wire()
-        return [DGKCiphertext.rows(cv[:, b], pub, fresh=True) for b in range(k)]
+        return [DGKCiphertext.rows(RowBlock(cv, b), pub, fresh=True) for b in range(k)]
 
     def _run_step_6_7(self, items: list) -> list:
         """Steps 6 and 7 of K sessions: one sc_initiator_step67 call; per session [[x <= y]]."""
         import numpy as np
 
+        from .coalesce import stack_blocks
+
         pai, l = self.scheme_paillier, self.l_maximum_bit_length
         e, nw, k = pai.engine, pai.mod_n.nwords, len(items)
-        three, shift = np.empty((3, k, 2 * nw), dtype="<u4"), np.empty((k, nw), dtype="<u4")
+        three, shift = stack_blocks([it[0] for it in items], 3, 2 * nw), np.empty((k, nw), dtype="<u4")
         for b, it in enumerate(items):
-            three[:, b], shift[b] = it[0], it[1][3]
+            shift[b] = it[1][3]
         t = e.upload_words(three)
         plain = AlicePlain(None, None, None, e.upload_u64([it[1][2] & 0xFFFFFFFFFFFFFFFF for it in items]), e.upload_words(shift))
         res = e.download_words(Initiator.step_6_7_batch(e.upload_u64([it[2] for it in items]), t[2], t[0], t[1], plain, l, pai))

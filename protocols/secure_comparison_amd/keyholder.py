@@ -172,6 +172,8 @@ class KeyHolder:
         fresh ciphertexts, and the rows of the two plaintext quotients zeta_1, zeta_2, which travel to step 5 with the session)."""
         import numpy as np
 
+        from .limbs import RowBlock
+
         pai, dgk, l = self.scheme_paillier, self.scheme_dgk, self.l_maximum_bit_length
         e, nw, k = pai.engine, pai.mod_n.nwords, len(items)
         er = (dgk.randomizer_bits + 31) // 32
@@ -186,7 +188,7 @@ class KeyHolder:
         pub = dgk.for_wire()
         out = []
         for b in range(k):
-            cts = DGKCiphertext.rows(planes[:, b], pub, fresh=True)
+            cts = DGKCiphertext.rows(RowBlock(planes, b), pub, fresh=True)
             out.append((cts[0], cts[1:], (z1[b], z2[b])))
         return out
 
@@ -195,13 +197,14 @@ class KeyHolder:
         time where every session of the batch has them, else computed in the call); per session the three fresh ciphertexts."""
         import numpy as np
 
-        from .coalesce import int_rows
+        from .coalesce import int_rows, stack_blocks
+        from .limbs import RowBlock
 
         pai, dgk, l = self.scheme_paillier, self.scheme_dgk, self.l_maximum_bit_length
         e, nw, nd, k = pai.engine, pai.mod_n.nwords, dgk.mod_n.nwords, len(items)
-        c, zeta = np.empty((l + 1, k, nd), dtype="<u4"), np.empty((2, k, nw), dtype="<u4")
+        c, zeta = stack_blocks([it[0] for it in items], l + 1, nd), np.empty((2, k, nw), dtype="<u4")      # the initiator's own array when the sessions are the same
         for b, it in enumerate(items):
-            c[:, b], zeta[0, b], zeta[1, b] = it[0], it[1][0], it[1][1]
+            zeta[0, b], zeta[1, b] = it[1][0], it[1][1]
         tz = e.upload_words(zeta)
         ready = all(it[3] is not None for it in items)
         if ready:
@@ -219,7 +222,7 @@ class KeyHolder:
         _, z1, z2, db = KeyHolder.step_4j_5_batch(e.upload_words(c), BobPlain(None, None, None, tz[0], tz[1]), pai, dgk, rho3, randomizers_ready=ready)
         out3 = np.stack([e.download_words(z1), e.download_words(z2), e.download_words(db)])       # [3][K][2nw]
         pub = pai.for_wire()
-        return [tuple(PaillierCiphertext.rows(out3[:, b], pub, fresh=True)) for b in range(k)]
+        return [tuple(PaillierCiphertext.rows(RowBlock(out3, b), pub, fresh=True)) for b in range(k)]
 
     async def perform_secure_comparison_batch(self, draws=None, source: str = "device", generator=None) -> None:
         """Bob's side of Initiator.perform_secure_comparison_batch.  `draws` (batch.BatchDraws; Bob's fields) injects

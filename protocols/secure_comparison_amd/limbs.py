@@ -33,3 +33,29 @@ def words_to_ints(arr: np.ndarray) -> list[int]:
     raw = flat.tobytes()
     step = 4 * n
     return [int.from_bytes(raw[i * step:(i + 1) * step], "little") for i in range(flat.shape[0])]
+
+
+class RowBlock:
+    """The rows that belong to ONE session inside a batch array: row j = base[j, b] of a bit-major host array [rows][K][words] (what a
+    batched step of K coalesced sessions downloads).  Ciphertext objects of a message refer to such a block and a row number instead of
+    holding Python integers; the next batched call recognises the whole batch by its blocks (coalesce.stack_blocks) and takes the
+    array back as it is."""
+
+    __slots__ = ("base", "b")
+
+    def __init__(self, base: np.ndarray, b: int) -> None:
+        self.base, self.b = base, b
+
+    def __len__(self) -> int:
+        return self.base.shape[0]
+
+    @property
+    def words(self) -> int:
+        return self.base.shape[-1]
+
+    def row(self, j: int) -> np.ndarray:
+        return self.base[j, self.b]
+
+    def array(self) -> np.ndarray:
+        """[rows][words] (a strided view)."""
+        return self.base[:, self.b]

@@ -20,6 +20,7 @@ from typing import Any
 import torch
 
 from . import keygen
+from .limbs import RowBlock
 
 WARN_INEFFICIENT_RANDOMIZATION = (
     "Randomizing a fresh ciphertext wastes randomness: the ciphertext was already randomized and unused."
@@ -106,7 +107,8 @@ class _Ciphertext:
 
     @classmethod
     def rows(cls, block, scheme: Any, fresh: bool = False) -> list:
-        """One ciphertext per row of `block` ([rows][nwords] words), in order -- what a batch launch hands to a session."""
+        """One ciphertext per row of `block` (an array [rows][nwords] of words, or a limbs.RowBlock), in order -- what a batch launch
+        hands to a session."""
         out = []
         for j in range(len(block)):
             c = object.__new__(cls)
@@ -117,7 +119,9 @@ class _Ciphertext:
     def _int(self) -> int:
         v = self._raw_value
         if v is None:
-            v = self._raw_value = int.from_bytes(self._block[self._row].tobytes(), "little")
+            blk = self._block
+            row = blk.row(self._row) if type(blk) is RowBlock else blk[self._row]
+            v = self._raw_value = int.from_bytes(row.tobytes(), "little")
         return v
 
     @property

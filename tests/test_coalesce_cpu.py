@@ -32,9 +32,15 @@ def test_concurrent_sessions_equal_the_uncoalesced_runs_message_by_message(world
     """24 concurrent perform_secure_comparison sessions on ONE Initiator / KeyHolder pair (the reference's test_parallel_runs shape,
     test/unit/test_secure_comparison.py:804-835, scaled up), strict warnings: every message of every session equals what the same
     session sends when it runs alone and uncoalesced with the same random stream; the steps really ran as batches."""
+    from protocols.secure_comparison_amd import coalesce
+
     eng, bob_p, bob_d = world
     pairs = [(23, 42), (42, 23), (7, 7), (-3, 5), (5, -3), (0, 0), (65535, 1), (1, 65535)] * 3
+    before = dict(coalesce.STACK_STATS)
     co_res, co_sent, stats = run_sessions(pairs, L, bob_p, bob_d, coalesce=True)
+    # both players coalesced the same sessions in the same order: the three big per-session arrays ([d] | [beta_i], [c_i], the three
+    # Paillier ciphertexts) went from one batched call to the next as the peer's own array, not block by block
+    assert coalesce.STACK_STATS["taken_whole"] - before["taken_whole"] == 3 and coalesce.STACK_STATS["assembled"] == before["assembled"]
     un_res, un_sent, _ = run_sessions(pairs, L, bob_p, bob_d, coalesce=False)
     assert co_sent.keys() == un_sent.keys() and len(co_sent) == 4 * len(pairs)
     for k in co_sent:
