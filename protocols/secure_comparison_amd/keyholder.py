@@ -180,11 +180,12 @@ class KeyHolder:
         z, exps = np.empty((k, 2 * nw), dtype="<u4"), np.empty((l + 1, k, er), dtype="<u4")
         for b, it in enumerate(items):
             z[b], exps[:, b] = it[0], it[1]
-        plain, d, beta = KeyHolder.step_2_4b_batch(e.upload_words(z), l, pai, dgk, e.upload_words(exps))
-        # [d] and the planes [beta_i] as ONE host array [l+1][K][nd]: a session's l + 1 ciphertexts are then consecutive rows of one
-        # block, which the initiator's next batched call takes back without converting a single integer (coalesce.rows_of)
-        planes = np.concatenate([e.download_words(d)[None], e.download_words(beta)])
-        z1, z2 = e.download_words(plain.zeta_1), e.download_words(plain.zeta_2)
+        assert dgk.public_key.u > (1 << (l + 2))
+        # (KeyHolder.step_2_4b_batch, keeping [d] and the planes [beta_i] as the ONE array [l+1][K][nd] the launch wrote: a session's
+        # l + 1 ciphertexts are then the rows of one block, which the initiator's next batched call takes back as it is)
+        _, _, _, zeta_1, zeta_2, enc = e.keyholder_step2_4b(pai.key, dgk.key, l, e.upload_words(z), e.upload_words(exps).reshape((l + 1) * k, er), False, None)
+        planes = e.download_words(enc)
+        z1, z2 = e.download_words(zeta_1), e.download_words(zeta_2)
         pub = dgk.for_wire()
         out = []
         for b in range(k):
