@@ -50,11 +50,24 @@ class StepCoalescer:
         self.max_batch = max(1, int(max_batch))
         self.linger_s = float(linger_s)
         self._queues: dict[str, _Queue] = {}
+        self.active = 0          # sessions of the player in flight (session())
         self.stats = {"calls": 0, "items": 0, "largest": 0, "fallbacks": 0, "seconds": {}}     # seconds: wall clock inside the batched calls, per step
 
-    async def submit(self, kind: str, run: Callable[[list], Sequence], item: Any) -> Any:
+    @contextlib.contextmanager
+    def session(self):
+        """Brackets one session of the player: the coalescer then knows how many sessions can still arrive at a step."""
+        self.active += 1
+        try:
+            yield
+        finally:
+            self.active -= 1
+
+    async def submit(self, kind: str, run: Callable[[list], Sequence], item: Any, first: bool = False) -> Any:
         """Queue `item` for the step `kind`; `run(items)` makes ONE batched call for a list of such items and returns one result per
-        item, in order.  Returns this item's result (or raises what its own execution raised)."""
+        item, in order.  Returns this item's result (or raises what its own execution raised).  The queue is executed at once when
+        every session in flight is waiting in it (nobody else can arrive: a lone session pays no extra turn of the event loop, a burst
+        that moves in lock step goes the moment its last session arrives) -- except for a session's `first` request, when sessions
+        created together may not all have started yet; otherwise after the first turn of the loop that brings no new request."""
         loop = asyncio.get_running_loop()
         q = self._queues.get(kind)
         if q is None:
@@ -67,6 +80,11 @@ class StepCoalescer:
         q.run = run
         if len(q.items) >= self.max_batch:
             self._flush(kind)
+        elif not first and 0 < self.active <= len(q.items):
+            # (as a callback of its own, not inside this session's task: the session would otherwise run ahead of the others -- its
+            # future is done before it awaits it -- and reach the peer first, and the peer's batch would no longer be in array order)
+            q.armed = True
+            loop.call_soon(self._flush, kind)
         elif not q.armed:
             q.armed, q.seen, q.lingered = True, 0, False
             loop.call_soon(self._tick, kind, loop)

@@ -77,7 +77,8 @@ class Initiator:
         sid = self.session_id
         await self.receive_encryption_schemes(sid)
         if self.fuse_steps and self.coalesce_sessions:
-            return await self._perform_coalesced(x, y, sid)
+            with self._coalescer().session():
+                return await self._perform_coalesced(x, y, sid)
         self._start_randomness_generation()
         l = self.l_maximum_bit_length
         pai, dgk = self.scheme_paillier, self.scheme_dgk
@@ -186,7 +187,7 @@ class Initiator:
         yv = (y.consume(), None) if isinstance(y, PaillierCiphertext) else (None, pai._encode(y))
         assert (1 << (l + 2)) < n // 2
         r = src.randbelow(n)                                                       # step 1 (:250)
-        z_enc, plain = await co.submit("step_1", self._run_step_1, (xv, yv, r, rho_z))
+        z_enc, plain = await co.submit("step_1", self._run_step_1, (xv, yv, r, rho_z), first=True)
         await self.communicator.send(self.other_party, z_enc, msg_id=f"step_1_session_{sid}")
         d_enc, beta_is_enc = await self.communicator.recv(self.other_party, msg_id=f"step_4b_session_{sid}")
         if len(beta_is_enc) != l:

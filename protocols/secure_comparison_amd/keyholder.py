@@ -68,7 +68,8 @@ class KeyHolder:
         sid = self.session_id
         await self.make_and_send_encryption_schemes(sid)
         if self.fuse_steps and self.coalesce_sessions:
-            await self._perform_coalesced(sid)
+            with self._coalescer().session():
+                await self._perform_coalesced(sid)
             return
         self._start_randomness_generation()
         l = self.l_maximum_bit_length
@@ -146,10 +147,10 @@ class KeyHolder:
         rho3 = rho[::-1]                        # the pool is used from its end: [[zeta_1]], [[zeta_2]], [[delta_B]] take draws 2, 1, 0
         ahead = None
         if self.background_randomness:          # the three Paillier randomizers are not needed before step 5: queued on the second context now
-            ahead = await co.submit("randomizers_step_5", self._run_randomizers_ahead, rho3)
+            ahead = await co.submit("randomizers_step_5", self._run_randomizers_ahead, rho3, first=True)
         z_enc = await self.communicator.recv(self.other_party, msg_id=f"step_1_session_{sid}")
         z_row = rows_of([z_enc], 2 * pai.mod_n.nwords)[0]
-        d_enc, beta_is_enc, zetas = await co.submit("step_2_4b", self._run_step_2_4b, (z_row, r_dgk[::-1]))   # [d] first, then [beta_i]
+        d_enc, beta_is_enc, zetas = await co.submit("step_2_4b", self._run_step_2_4b, (z_row, r_dgk[::-1]), first=ahead is None)   # [d] first, then [beta_i]
         await self.communicator.send(self.other_party, (d_enc, beta_is_enc), msg_id=f"step_4b_session_{sid}")
         c_is_enc = await self.communicator.recv(self.other_party, msg_id=f"step_4i_session_{sid}")
         if len(c_is_enc) != l + 1:

@@ -136,3 +136,36 @@ def test_coalescer_scheduling():
 
     out = asyncio.run(cancelled(StepCoalescer(linger_s=0.05)))
     assert isinstance(out[0], asyncio.CancelledError) and out[1] == 20
+
+
+def test_a_step_runs_the_moment_every_session_in_flight_waits_in_it():
+    """A player's sessions register with its coalescer (StepCoalescer.session): a queue that holds a request of EVERY session in flight
+    cannot grow, so it is executed without the quiet turn of the event loop a partial queue waits for -- a lone session pays no extra
+    turn, a burst in lock step goes when its last session arrives; a session's `first` request never takes that short cut (sessions
+    created together may not all have started), and results come back in the order the sessions queued."""
+    calls, turns = [], []
+
+    def run(items):
+        calls.append(list(items))
+        return [10 * i for i in items]
+
+    async def go():
+        co = StepCoalescer()
+        loop = asyncio.get_running_loop()
+
+        async def session(i):
+            with co.session():
+                a = await co.submit("one", run, i, first=True)
+                t0 = loop.time()
+                b = await co.submit("two", run, i + 100)
+                turns.append(loop.time() - t0)
+                return a, b
+
+        out = await asyncio.gather(*(session(i) for i in range(5)))
+        assert co.active == 0
+        lone = await session(9)
+        return out, lone
+
+    out, lone = asyncio.run(go())
+    assert out == [(10 * i, 10 * (i + 100)) for i in range(5)] and lone == (90, 1090)
+    assert calls == [[0, 1, 2, 3, 4], [100, 101, 102, 103, 104], [9], [109]]
