@@ -126,11 +126,12 @@ class KeyHolder:
         """See Initiator._draws."""
         src = self.__dict__.get("draw_source")
         if src is None:
-            src = self.__dict__.get("_host_draws")
+            eng = self.scheme_paillier.engine            # one buffered stream per engine: players come and go (one pair per connection),
+            src = eng.__dict__.get("_host_draws")        # a refill is a megabyte
             if src is None:
                 from .host_draws import HostDraws
 
-                src = self.__dict__["_host_draws"] = HostDraws.from_engine(self.scheme_paillier.engine)
+                src = eng.__dict__["_host_draws"] = HostDraws.from_engine(eng)
         return src
 
     async def _perform_coalesced(self, sid: int) -> None:
