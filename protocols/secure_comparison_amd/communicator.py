@@ -105,9 +105,14 @@ class StreamCommunicator:
 
     device_tensors = False
 
-    def __init__(self, sock, alloc=None, timeout_s: float | None = 600.0) -> None:
+    def __init__(self, sock, alloc=None, timeout_s: float | None = 600.0, max_payload: int = 1 << 32, max_pending: int = 1 << 34) -> None:
+        """max_payload: the largest frame accepted from the peer (the largest batch message of BASELINE's configurations is 1.1 GB);
+        max_pending: the most bytes held for messages nobody has asked for yet.  Both bound what a misbehaving peer can make this
+        process allocate: a frame beyond them closes the connection."""
         sock.setblocking(False)
         self.sock, self.timeout_s = sock, timeout_s
+        self.max_payload, self.max_pending = int(max_payload), int(max_pending)
+        self._pending = 0
         self._alloc = alloc if alloc is not None else bytearray
         self._box: dict[str, Any] = {}
         self._waiters: dict[str, asyncio.Future] = {}
@@ -116,7 +121,7 @@ class StreamCommunicator:
         self._send_lock: asyncio.Lock | None = None
 
     @classmethod
-    async def open_unix(cls, path: str, alloc=None, wait_s: float = 60.0) -> "StreamCommunicator":
+    async def open_unix(cls, path: str, alloc=None, wait_s: float = 60.0, **options) -> "StreamCommunicator":
         """Connect to a listening Unix socket (waiting for the peer to start listening)."""
         import os
         import socket
@@ -129,7 +134,7 @@ class StreamCommunicator:
                 if not os.path.exists(path):
                     raise FileNotFoundError(path)
                 await loop.sock_connect(sock, path)
-                return cls(sock, alloc)
+                return cls(sock, alloc, **options)
             except (FileNotFoundError, ConnectionRefusedError):
                 sock.close()
                 if loop.time() > t_end:
@@ -137,7 +142,7 @@ class StreamCommunicator:
                 await asyncio.sleep(0.05)
 
     @classmethod
-    async def accept_unix(cls, path: str, alloc=None) -> "StreamCommunicator":
+    async def accept_unix(cls, path: str, alloc=None, **options) -> "StreamCommunicator":
         """Listen on a Unix socket and return the communicator of the first connection."""
         import socket
 
@@ -149,7 +154,7 @@ class StreamCommunicator:
             conn, _ = await asyncio.get_running_loop().sock_accept(srv)
         finally:
             srv.close()
-        return cls(conn, alloc)
+        return cls(conn, alloc, **options)
 
     async def _read_exact(self, loop, view: memoryview) -> None:
         got = 0
@@ -172,8 +177,12 @@ class StreamCommunicator:
                 await self._read_exact(loop, memoryview(rest))
                 msg_id = bytes(rest[:n]).decode()
                 (size,) = struct.unpack("<Q", rest[n:])
-                if size > (1 << 40):
-                    raise ValueError("malformed frame (payload length)")
+                if size > self.max_payload:
+                    raise ValueError(f"frame {msg_id!r} announces {size} bytes, more than max_payload = {self.max_payload}")
+                if msg_id in self._box:
+                    raise ValueError(f"second message {msg_id!r} while the first is still unclaimed")
+                if msg_id not in self._waiters and self._pending + size > self.max_pending:
+                    raise ValueError(f"more than max_pending = {self.max_pending} bytes of unclaimed messages")
                 payload = self._alloc(size)
                 if size:
                     await self._read_exact(loop, memoryview(payload).cast("B"))
@@ -182,7 +191,8 @@ class StreamCommunicator:
                     fut.set_result(payload)
                 else:
                     self._box[msg_id] = payload
-        except (ConnectionError, OSError, ValueError) as exc:
+                    self._pending += size
+        except Exception as exc:  # noqa: BLE001 -- whatever ends the reader (the peer, a malformed frame, a failed allocation) ends every wait
             self._closed = exc
             for fut in self._waiters.values():
                 if not fut.done():
@@ -207,7 +217,9 @@ class StreamCommunicator:
         if self._pump is None:
             self._pump = asyncio.ensure_future(self._read_frames())
         if msg_id in self._box:
-            return self._box.pop(msg_id)
+            payload = self._box.pop(msg_id)
+            self._pending -= len(memoryview(payload).cast("B"))
+            return payload
         if self._closed is not None:
             raise ConnectionError(f"connection closed: {self._closed!r}")
         fut = asyncio.get_running_loop().create_future()

@@ -148,3 +148,38 @@ def test_two_processes_over_a_socket(keys, tmp_path):
         if child.is_alive():
             child.kill()
     assert child.exitcode == 0
+
+
+def test_stream_frames_are_bounded_before_anything_is_allocated():
+    """A peer decides what the frame headers say: a payload beyond max_payload, a pile of messages nobody asked for beyond max_pending,
+    or a second message under an unclaimed id end the connection with the reason -- before a buffer of the announced size exists."""
+    import socket
+    import struct
+
+    from protocols.secure_comparison_amd import StreamCommunicator
+
+    def frame(msg_id, payload, announce=None):
+        ident = msg_id.encode()
+        return struct.pack("<I", len(ident)) + ident + struct.pack("<Q", len(payload) if announce is None else announce) + payload
+
+    async def case(frames, ask, **limits):
+        a, b = socket.socketpair()
+        sizes = []
+        comm = StreamCommunicator(a, alloc=lambda n: sizes.append(n) or bytearray(n), timeout_s=5, **limits)
+        b.sendall(b"".join(frames))
+        try:
+            return bytes(await comm.recv("peer", ask)), sizes
+        finally:
+            await comm.close()
+            b.close()
+
+    got, sizes = asyncio.run(case([frame("m1", b"abc"), frame("m2", b"defg")], "m2", max_payload=8, max_pending=8))
+    assert got == b"defg" and sizes == [3, 4]
+    with pytest.raises(ConnectionError, match="max_payload"):
+        asyncio.run(case([frame("big", b"", announce=1 << 50)], "big", max_payload=1 << 20))
+    with pytest.raises(ConnectionError, match="max_pending"):
+        asyncio.run(case([frame(f"u{i}", b"x" * 6) for i in range(3)], "never", max_payload=8, max_pending=16))
+    with pytest.raises(ConnectionError, match="second message"):
+        asyncio.run(case([frame("dup", b"1"), frame("dup", b"2")], "other"))
+    with pytest.raises(ConnectionError, match="message id length"):
+        asyncio.run(case([struct.pack("<I", 1 << 30)], "x"))
