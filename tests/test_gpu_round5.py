@@ -126,19 +126,21 @@ def test_pair_segment_policy_follows_the_measured_hold_time(engine, keys):
     assert engine.download(whole[:2]) == [pow(v, sk.n, sk.n * sk.n) for v in base[:2]]
 
 
-def test_two_os_processes_share_the_gpu_over_a_socket(tmp_path):
+@pytest.mark.parametrize("sessions,chunks", [(1, 3), (2, 1)])
+def test_two_os_processes_share_the_gpu_over_a_socket(tmp_path, sessions, chunks):
     """The reference's players are separate processes (SC/test/integration/test_pool.py:41-73).  tools/gpu_two_process.py starts the
     key holder and the initiator as two fresh OS processes -- own HIP contexts on this one GPU, a Unix socket between them
     (communicator.StreamCommunicator, wire.py byte messages into pinned buffers), draws on each party's device generator -- and
-    the key holder's process decrypts the initiator's results: every row x <= y.  A small batch here; the throughput figures are
-    in profiles/r05_two_process.txt."""
+    the key holder's process decrypts the initiator's results: every row x <= y.  sessions = 2: two free-running sessions per process,
+    each with its own thread, library context and socket.  A small batch here; the throughput figures are in
+    profiles/r05_two_process.txt."""
     import json
     import subprocess
 
     from conftest import ROOT
 
     cp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_two_process.py"), "--batch", "1536", "--l", "16", "--pbits", "2048",
-                         "--batches", "2", "--chunks", "3", "--window", "8"], capture_output=True, text=True, timeout=600)
+                         "--batches", "2", "--chunks", str(chunks), "--window", "8", "--sessions", str(sessions)], capture_output=True, text=True, timeout=600)
     assert cp.returncode == 0, cp.stderr[-2000:]
     line = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
