@@ -552,7 +552,7 @@ def test_pair_arithmetic_modexp(engine, bits):
     m = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
     mm, mm2 = engine.modulus(m), engine.modulus(m * m, 2 * ((bits + 31) // 32))
     assert engine.supports_sq(mm)
-    B = 24
+    B = 24 if bits < 3072 else 12              # (the L = 14 twin of 3072 bits holds 8 numbers per wave: still more than one wave)
     for mult, xs in ((1, [rng.randrange(m) for _ in range(B)]), (2, [rng.randrange(m * m) for _ in range(B)]), (4, [rng.getrandbits(4 * bits) for _ in range(B)])):
         xs[:5] = [1, 0, m - 1, m if mult > 1 else 2, (m * m - 1) if mult > 1 else m - 2]
         t = engine.upload(xs, mult * mm.nwords)
