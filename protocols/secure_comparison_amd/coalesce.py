@@ -41,9 +41,11 @@ class _Queue:
 class StepCoalescer:
     """Gathers the step requests of the concurrent sessions of ONE player object.
 
-    max_batch: a queue that reaches this many requests is executed at once.  linger_s: after the first quiet turn of the event loop
-    wait this much longer for stragglers (0: execute at once; a transport between two hosts delivers the messages of concurrent
-    sessions microseconds to milliseconds apart).  The batched call itself runs synchronously on the event loop's thread, like every
+    max_batch: a queue that reaches this many requests is executed at once.  linger_s: after a turn of the event loop that brought
+    no new request, wait this much longer for stragglers -- again after every straggler, so a queue is executed once nothing has
+    arrived for linger_s (0: at the first quiet turn; a transport between two processes or hosts delivers the messages of concurrent
+    sessions a socket read apart -- microseconds to milliseconds -- and a batch cut in two there stays cut for the rest of the
+    protocol: tools/gpu_two_process_sessions.py).  The batched call itself runs synchronously on the event loop's thread, like every
     GPU call of the single path."""
 
     def __init__(self, max_batch: int = 4096, linger_s: float = 0.0) -> None:
@@ -95,7 +97,7 @@ class StepCoalescer:
         if q is None or not q.armed:
             return
         if len(q.items) != q.seen:                 # the queue grew during the last turn: sessions are still arriving
-            q.seen = len(q.items)
+            q.seen, q.lingered = len(q.items), False           # (and the wait for stragglers starts again after the last arrival)
             loop.call_soon(self._tick, kind, loop)
         elif self.linger_s > 0 and not q.lingered:
             q.lingered = True

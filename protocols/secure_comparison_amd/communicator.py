@@ -41,12 +41,6 @@ class InMemoryCommunicator:
         # of bytes.  False makes the batch protocol serialize as it would for a real transport (one pinned host buffer).
         self.device_tensors = device_tensors
 
-    def _watch(self, loop, fut) -> None:
-        if self.__dict__.get("_watch_loop") is not loop:
-            self._watched, self._watch_loop = [], loop
-            loop.call_later(min(1.0, max(0.01, self.timeout_s)), _check_deadlines, self, loop)
-        self._watched.append(fut)
-
     def peer(self) -> "InMemoryCommunicator":
         """A second endpoint on the same mailbox (hand it to the other player)."""
         return InMemoryCommunicator(self.mailbox, self.max_polls, self.device_tensors, self.timeout_s)
@@ -81,7 +75,7 @@ class InMemoryCommunicator:
             # one watchdog per endpoint and event loop instead of a timer per receive (a thousand sessions wait at once)
             fut._sc_deadline = loop.time() + self.timeout_s        # type: ignore[attr-defined]
             fut._sc_what = (msg_id, party_id)                      # type: ignore[attr-defined]
-            self._watch(loop, fut)
+            _watch(self, loop, fut)
         try:
             return await fut
         finally:
@@ -100,12 +94,16 @@ class StreamCommunicator:
     straight from the sender's buffer (the pinned message the kernels wrote, wire.reserve) and are received with
     `loop.sock_recv_into` into a buffer from `alloc(nbytes)` -- hand in wire.pinned_buffer and a batch message lands in pinned host
     memory, from where the host-to-device copies run on an SDMA engine without a staging copy.  Carries what the batch protocol puts
-    on a byte transport (wire.py) and JSON scheme documents; ciphertext OBJECTS of the single-comparison protocol need a serializer
-    of their own and are refused."""
+    on a byte transport (wire.py) and JSON scheme documents -- and the ONE-comparison protocol's messages: the scheme pair travels as
+    its public document, ciphertexts / lists / tuples of them in wire.pack_session_message's form once `bind_schemes` has named
+    the schemes they belong to (Initiator and KeyHolder do that themselves), so that the reference's call shape -- many concurrent
+    `perform_secure_comparison` sessions, SC/initiator.py:69-175 -- runs between two processes, each coalescing its own sessions'
+    steps into batch launches (coalesce.py)."""
 
     device_tensors = False
 
-    def __init__(self, sock, alloc=None, timeout_s: float | None = 600.0, max_payload: int = 1 << 32, max_pending: int = 1 << 34) -> None:
+    def __init__(self, sock, alloc=None, timeout_s: float | None = 600.0, max_payload: int = 1 << 32, max_pending: int = 1 << 34,
+                 engine=None) -> None:
         """max_payload: the largest frame accepted from the peer (the largest batch message of BASELINE's configurations is 1.1 GB);
         max_pending: the most bytes held for messages nobody has asked for yet.  Both bound what a misbehaving peer can make this
         process allocate: a frame beyond them closes the connection."""
@@ -113,6 +111,9 @@ class StreamCommunicator:
         self.sock, self.timeout_s = sock, timeout_s
         self.max_payload, self.max_pending = int(max_payload), int(max_pending)
         self._pending = 0
+        self.engine = engine                 # for the scheme objects made of a received scheme document (None: the default engine)
+        self._schemes = None
+        self._scheme_docs: dict[str, Any] = {}
         self._alloc = alloc if alloc is not None else bytearray
         self._box: dict[str, Any] = {}
         self._waiters: dict[str, asyncio.Future] = {}
@@ -156,6 +157,11 @@ class StreamCommunicator:
             srv.close()
         return cls(conn, alloc, **options)
 
+    def bind_schemes(self, paillier, dgk) -> None:
+        """The schemes whose ciphertexts this connection carries for the ONE-comparison protocol (wire.pack_session_message): objects
+        that arrive are bound to them.  Initiator and KeyHolder call this themselves once they hold their schemes."""
+        self._schemes = (paillier, dgk)
+
     async def _read_exact(self, loop, view: memoryview) -> None:
         got = 0
         while got < len(view):
@@ -165,27 +171,51 @@ class StreamCommunicator:
             got += n
 
     async def _read_frames(self) -> None:
+        """Frames out of a read buffer filled 256 KB at a time (a burst of a thousand sessions is thousands of frames of a few KB:
+        one wake-up per chunk, not three per frame); a payload of a megabyte or more -- a batch message -- is received straight into a
+        buffer from `alloc`, smaller ones are delivered as `bytes` of their own."""
         loop = asyncio.get_running_loop()
-        head = bytearray(4)
+        buf, off = bytearray(), 0
+        chunk = memoryview(bytearray(1 << 18))
+
+        async def fill(need: int) -> None:
+            nonlocal buf, off
+            while len(buf) - off < need:
+                if off > (1 << 16) and 2 * off > len(buf):
+                    del buf[:off]
+                    off = 0
+                n = await loop.sock_recv_into(self.sock, chunk)
+                if n == 0:
+                    raise ConnectionError("peer closed the connection")
+                buf += chunk[:n]
+
         try:
             while True:
-                await self._read_exact(loop, memoryview(head))
-                (n,) = struct.unpack("<I", head)
+                await fill(4)
+                (n,) = struct.unpack_from("<I", buf, off)
                 if n > 4096:
                     raise ValueError("malformed frame (message id length)")
-                rest = bytearray(n + 8)
-                await self._read_exact(loop, memoryview(rest))
-                msg_id = bytes(rest[:n]).decode()
-                (size,) = struct.unpack("<Q", rest[n:])
+                await fill(n + 12)
+                msg_id = bytes(buf[off + 4:off + 4 + n]).decode()
+                (size,) = struct.unpack_from("<Q", buf, off + 4 + n)
+                off += n + 12
                 if size > self.max_payload:
                     raise ValueError(f"frame {msg_id!r} announces {size} bytes, more than max_payload = {self.max_payload}")
                 if msg_id in self._box:
                     raise ValueError(f"second message {msg_id!r} while the first is still unclaimed")
                 if msg_id not in self._waiters and self._pending + size > self.max_pending:
                     raise ValueError(f"more than max_pending = {self.max_pending} bytes of unclaimed messages")
-                payload = self._alloc(size)
-                if size:
-                    await self._read_exact(loop, memoryview(payload).cast("B"))
+                if size < _DIRECT:
+                    await fill(size)
+                    payload = bytes(buf[off:off + size])
+                    off += size
+                else:
+                    payload = self._alloc(size)
+                    view = memoryview(payload).cast("B")
+                    have = min(len(buf) - off, size)
+                    view[:have] = buf[off:off + have]
+                    off += have
+                    await self._read_exact(loop, view[have:])
                 fut = self._waiters.pop(msg_id, None)
                 if fut is not None and not fut.done():
                     fut.set_result(payload)
@@ -199,18 +229,52 @@ class StreamCommunicator:
                     fut.set_exception(ConnectionError(f"connection closed while waiting: {exc!r}"))
             self._waiters.clear()
 
-    async def send(self, party_id: str, message: Any, msg_id: str) -> None:
+    def _encode(self, message: Any):
+        """Bytes as they are; the scheme pair of `make_and_send_encryption_schemes` as its public document; ciphertexts, lists and tuples
+        of them in wire.py's form for the one-comparison protocol (after what every serializing transport does to them: a ciphertext
+        that is not fresh is randomized, with a warning, and the sender's copy stops being fresh)."""
         try:
-            payload = memoryview(message).cast("B")
+            return memoryview(message).cast("B")
         except TypeError:
-            raise TypeError(f"StreamCommunicator carries bytes (batch messages, scheme documents), not {type(message).__name__}") from None
+            pass
+        from . import wire
+
+        if type(message) is tuple and len(message) == 2 and all(hasattr(m, "public_key") for m in message):
+            return _SCHEMES_MAGIC + wire.pack_public_schemes(*message)
+        if self._schemes is None:
+            raise TypeError(f"StreamCommunicator carries bytes and, once bind_schemes() has named the schemes, ciphertexts; not {type(message).__name__}")
+        return wire.pack_session_message(_as_on_wire(message), *self._schemes)
+
+    def _decode(self, payload: Any) -> Any:
+        view = memoryview(payload).cast("B")
+        head = bytes(view[:4])
+        if head == _OBJ_MAGIC:
+            if self._schemes is None:
+                raise ValueError("a ciphertext message arrived before bind_schemes() named this party's schemes")
+            from . import wire
+
+            return wire.unpack_session_message(payload, *self._schemes)
+        if head == _SCHEMES_MAGIC:
+            doc = bytes(view[4:])
+            if self._scheme_docs.get("doc") != doc:          # every session announces the schemes again: one pair of objects per document
+                from . import wire
+
+                self._scheme_docs = {"doc": doc, "schemes": wire.unpack_public_schemes(doc, self.engine)}
+            return self._scheme_docs["schemes"]
+        return payload
+
+    async def send(self, party_id: str, message: Any, msg_id: str) -> None:
+        payload = self._encode(message)
         loop = asyncio.get_running_loop()
         if self._send_lock is None:
             self._send_lock = asyncio.Lock()
         ident = msg_id.encode()
+        head = struct.pack("<I", len(ident)) + ident + struct.pack("<Q", len(payload))
         async with self._send_lock:                      # frames of concurrent sub-sessions must not interleave
-            await loop.sock_sendall(self.sock, struct.pack("<I", len(ident)) + ident + struct.pack("<Q", len(payload)))
-            if len(payload):
+            if len(payload) < (1 << 16):
+                await loop.sock_sendall(self.sock, head + bytes(payload))
+            else:
+                await loop.sock_sendall(self.sock, head)
                 await loop.sock_sendall(self.sock, payload)
 
     async def recv(self, party_id: str, msg_id: str) -> Any:
@@ -219,15 +283,18 @@ class StreamCommunicator:
         if msg_id in self._box:
             payload = self._box.pop(msg_id)
             self._pending -= len(memoryview(payload).cast("B"))
-            return payload
+            return self._decode(payload)
         if self._closed is not None:
             raise ConnectionError(f"connection closed: {self._closed!r}")
-        fut = asyncio.get_running_loop().create_future()
+        loop = asyncio.get_running_loop()
+        fut = loop.create_future()
         self._waiters[msg_id] = fut
+        if self.timeout_s is not None:                   # one watchdog per connection, not a timer per receive
+            fut._sc_deadline = loop.time() + self.timeout_s        # type: ignore[attr-defined]
+            fut._sc_what = (msg_id, party_id)                      # type: ignore[attr-defined]
+            _watch(self, loop, fut)
         try:
-            return await (fut if self.timeout_s is None else asyncio.wait_for(fut, self.timeout_s))
-        except asyncio.TimeoutError:
-            raise TimeoutError(f"no message {msg_id!r} from {party_id!r}") from None
+            return self._decode(await fut)
         finally:
             self._waiters.pop(msg_id, None)
 
@@ -241,7 +308,18 @@ class StreamCommunicator:
         self.sock.close()
 
 
-def _check_deadlines(comm: "InMemoryCommunicator", loop) -> None:
+_DIRECT = 1 << 20            # payloads from this size on are received straight into a buffer from `alloc`
+_OBJ_MAGIC, _SCHEMES_MAGIC = b"SCO1", b"SCS1"
+
+
+def _watch(comm, loop, fut) -> None:
+    if comm.__dict__.get("_watch_loop") is not loop:
+        comm._watched, comm._watch_loop = [], loop
+        loop.call_later(min(1.0, max(0.01, comm.timeout_s)), _check_deadlines, comm, loop)
+    comm._watched.append(fut)
+
+
+def _check_deadlines(comm, loop) -> None:
     now, alive = loop.time(), []
     for fut in comm._watched:
         if fut.done():

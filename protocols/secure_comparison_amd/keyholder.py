@@ -67,6 +67,9 @@ class KeyHolder:
         self.session_id += 1
         sid = self.session_id
         await self.make_and_send_encryption_schemes(sid)
+        bind = getattr(self.communicator, "bind_schemes", None)
+        if bind is not None:                       # a byte transport builds the ciphertext objects it delivers on these schemes
+            bind(self.scheme_paillier, self.scheme_dgk)
         if self.fuse_steps and self.coalesce_sessions:
             with self._coalescer().session():
                 await self._perform_coalesced(sid)

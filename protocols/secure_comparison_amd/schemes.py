@@ -106,11 +106,11 @@ class _Ciphertext:
         self._fresh = fresh
 
     @classmethod
-    def rows(cls, block, scheme: Any, fresh: bool = False) -> list:
+    def rows(cls, block, scheme: Any, fresh: bool = False, start: int = 0, count: int | None = None) -> list:
         """One ciphertext per row of `block` (an array [rows][nwords] of words, or a limbs.RowBlock), in order -- what a batch launch
-        hands to a session."""
+        hands to a session; `start`, `count`: only that run of rows."""
         out = []
-        for j in range(len(block)):
+        for j in range(start, len(block) if count is None else start + count):
             c = object.__new__(cls)
             c._raw_value, c._block, c._row, c.scheme, c._fresh = None, block, j, scheme, fresh
             out.append(c)

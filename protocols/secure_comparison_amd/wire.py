@@ -498,3 +498,121 @@ def unpack_public_schemes(buf: bytes, engine=None):
     return (Paillier(int(doc["paillier"]["n"], 16), engine=engine),
             DGK(int(d["n"], 16), int(d["g"], 16), int(d["h"], 16), int(d["u"], 16), d["t"], engine=engine,
                 randomizer_bits=d["randomizer_bits"], fixed_base_window=d["fixed_base_window"]))
+
+
+# ---- messages of the ONE-comparison protocol as bytes -----------------------------------------------------------------------------------
+# The reference hands ciphertext OBJECTS to its transport, whose serializer (tno.mpc.communication + the schemes' hooks: out of scope,
+# SURVEY 2.2) turns each into bytes and finds the receiver's scheme instance again.  This is the minimal equivalent for the four
+# messages of SC/initiator.py:69-175 / SC/keyholder.py:80-133, so that concurrent single comparisons can run between two processes:
+#
+#     message = magic "SCO1" | paillier words u16 | dgk words u16 | shape length u32 | shape | rows (little-endian words, in order)
+#     shape   = 'P' | 'D'                       one Paillier / DGK ciphertext
+#             | 'L' count u32 shape*            a list            | 'T' count u32 shape*      a tuple
+#
+# The receiver binds every ciphertext to ITS scheme objects and checks the word counts against them; the rows of a list stay one
+# array (coalesce.rows_of hands them to the next batched step without making integers).
+OBJ_MAGIC = b"SCO1"
+
+
+def pack_session_message(message: Any, paillier, dgk) -> bytes:
+    """`message` -- what a transport's serializer would see, i.e. after communicator._as_on_wire -- as bytes."""
+    from .coalesce import rows_of
+    from .schemes import DGKCiphertext, PaillierCiphertext
+
+    pw, dw = 2 * paillier.mod_n.nwords, dgk.mod_n.nwords
+    leaf = {PaillierCiphertext: (0x50, pw), DGKCiphertext: (0x44, dw)}
+    shape, rows = bytearray(), []
+
+    def walk(m: Any) -> None:
+        kind = type(m)
+        if kind in leaf:
+            tag, nwords = leaf[kind]
+            shape.append(tag)
+            rows.append(rows_of([m], nwords))
+        elif kind is list or kind is tuple:
+            shape.append(0x4C if kind is list else 0x54)
+            shape.extend(struct.pack("<I", len(m)))
+            first = type(m[0]) if m else None
+            if first in leaf and all(type(c) is first for c in m):      # the l + 1 values of steps 4b / 4i, the three of step 5: one block
+                tag, nwords = leaf[first]
+                shape.extend(bytes([tag]) * len(m))
+                rows.append(rows_of(m, nwords))
+            else:
+                for c in m:
+                    walk(c)
+        else:
+            raise TypeError(f"the one-comparison protocol sends ciphertexts, lists and tuples of them, not {kind.__name__}")
+
+    walk(message)
+    shape.extend(b"\0" * (-len(shape) % 4))                             # (rows start on a word boundary)
+    parts = [OBJ_MAGIC, struct.pack("<HHI", pw, dw, len(shape)), bytes(shape)]
+    for r in rows:
+        parts.append(np.ascontiguousarray(r.array() if hasattr(r, "array") else r, dtype="<u4").tobytes())
+    out = b"".join(parts)
+    STATS["bytes"] += len(out)
+    return out
+
+
+def unpack_session_message(buf: Any, paillier, dgk) -> Any:
+    """Inverse of pack_session_message, bound to the receiver's schemes.  Nothing is trusted: word counts must be this party's, the
+    shape must parse completely and the rows must fill the message exactly."""
+    from .schemes import DGKCiphertext, PaillierCiphertext
+
+    mv = _as_view(buf)
+    if len(mv) < 12 or bytes(mv[:4]) != OBJ_MAGIC:
+        raise ValueError("not a message of the one-comparison protocol")
+    pw, dw, ns = struct.unpack("<HHI", mv[4:12])
+    if pw != 2 * paillier.mod_n.nwords or dw != dgk.mod_n.nwords:
+        raise ValueError(f"message carries {pw}- / {dw}-word ciphertexts, this party's schemes have {2 * paillier.mod_n.nwords} / {dgk.mod_n.nwords}")
+    if ns > (1 << 20) or 12 + ns > len(mv) or ns % 4 or (len(mv) - 12 - ns) % 4:
+        raise ValueError("malformed message (shape length)")
+    shape = bytes(mv[12:12 + ns])
+    words = np.frombuffer(mv[12 + ns:], dtype="<u4")
+    leaf = {0x50: (PaillierCiphertext, paillier, pw), 0x44: (DGKCiphertext, dgk, dw)}
+    pos, at = 0, 0
+    # a message of one kind of ciphertext -- all four of the protocol are -- is ONE array of rows, whatever its nesting: ([d], [[beta_i]])
+    # arrives as rows 0 .. l of one block, and the next batched step takes them as a slice (coalesce.rows_of)
+    wholes: dict[int, np.ndarray] = {}
+
+    def take(tag: int, count: int) -> list:
+        nonlocal at
+        cls, scheme, nwords = leaf[tag]
+        if at + count * nwords > len(words):
+            raise ValueError("malformed message (fewer rows than the shape announces)")
+        if at % nwords == 0 and len(words) % nwords == 0:
+            whole = wholes.get(nwords)
+            if whole is None:
+                whole = wholes[nwords] = words.reshape(-1, nwords)
+            out = cls.rows(whole, scheme, start=at // nwords, count=count)
+        else:
+            out = cls.rows(words[at:at + count * nwords].reshape(count, nwords), scheme)
+        at += count * nwords
+        return out
+
+    def walk(depth: int) -> Any:
+        nonlocal pos
+        if pos >= len(shape) or depth > 4:
+            raise ValueError("malformed message (shape)")
+        tag = shape[pos]
+        pos += 1
+        if tag in leaf:
+            return take(tag, 1)[0]
+        if tag in (0x4C, 0x54):
+            if pos + 4 > len(shape):
+                raise ValueError("malformed message (shape)")
+            (count,) = struct.unpack("<I", shape[pos:pos + 4])
+            pos += 4
+            if count > len(shape) - pos:
+                raise ValueError("malformed message (element count)")
+            if count and shape[pos] in leaf and shape[pos:pos + count] == bytes([shape[pos]]) * count:
+                items = take(shape[pos], count)
+                pos += count
+            else:
+                items = [walk(depth + 1) for _ in range(count)]
+            return items if tag == 0x4C else tuple(items)
+        raise ValueError("malformed message (unknown shape tag)")
+
+    out = walk(0)
+    if shape[pos:].strip(b"\0") or at != len(words):
+        raise ValueError("malformed message (trailing bytes)")
+    return out

@@ -145,3 +145,22 @@ def test_two_os_processes_share_the_gpu_over_a_socket(tmp_path, sessions, chunks
     line = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["two_process"] and d["rows_checked"] == 1536 and d["rows_decrypting_to_x_le_y"] == 1536 and d["value"] > 0
+
+
+def test_concurrent_single_comparisons_between_two_os_processes():
+    """The reference's call shape between two OS processes on the GPU: tools/gpu_two_process_sessions.py runs 48 concurrent
+    `perform_secure_comparison` sessions per burst on one Initiator and one KeyHolder in separate processes (own HIP contexts), the
+    ciphertext messages as bytes over a Unix socket, each side coalescing its sessions' steps; the key holder's process decrypts the
+    initiator's results: every row [x <= y], and the sessions really shared launches."""
+    import json
+    import subprocess
+
+    from conftest import ROOT
+
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_two_process_sessions.py"), "--sessions", "48", "--bursts", "2", "--l", "16",
+                         "--pbits", "1024"], capture_output=True, text=True, timeout=600)
+    assert cp.returncode == 0, cp.stderr[-2000:]
+    d = json.loads([ln for ln in cp.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["two_process_sessions"] and d["rows_checked"] == 48 and d["rows_decrypting_to_x_le_y"] == 48
+    for side in ("initiator_batched_calls", "keyholder_batched_calls"):
+        assert d[side]["items"] == 3 * 48 * 3 and d[side]["fallbacks"] == 0 and d[side]["calls"] < d[side]["items"] // 4, d[side]
