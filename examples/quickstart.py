@@ -1,8 +1,10 @@
-"""Quick start on an MI355X: the two ways to use the package.
+"""Quick start on an MI355X: the three ways to use the package.
 
 1. The reference-style single comparison: Initiator / KeyHolder coroutines over a transport
    (same flow as the usage example in the reference's README, with an in-memory transport instead of HTTP pools).
-2. The batched path: thousands of comparisons per call on device arrays.
+2. Many single comparisons at once: concurrent sessions on one player pair (the reference's test_parallel_runs shape); their steps
+   are coalesced into batch launches behind the same coroutine API.
+3. The batched path: thousands of comparisons per call on device arrays.
 
 Run:  python examples/quickstart.py   (needs the GPU; builds nothing -- run `python -m protocols.secure_comparison_amd.build` first)
 """
@@ -36,6 +38,21 @@ async def single_comparison() -> None:
     return paillier, dgk
 
 
+async def concurrent_singles(paillier: Paillier, dgk: DGK, sessions: int = 256) -> None:
+    l = 16
+    to_bob = InMemoryCommunicator()
+    alice = Initiator(l, communicator=to_bob, other_party="bob")
+    bob = KeyHolder(l, communicator=to_bob.peer(), other_party="alice", scheme_paillier=paillier, scheme_dgk=dgk)
+    pairs = [(i * 257 % (1 << l), i * 911 % (1 << l)) for i in range(sessions)]
+    t0 = time.perf_counter()
+    results = await asyncio.gather(*(alice.perform_secure_comparison(x, y) for x, y in pairs),        # plaintext inputs are encrypted on the way
+                                   *(bob.perform_secure_comparison() for _ in pairs))
+    dt = time.perf_counter() - t0
+    ok = all(bool(paillier.decrypt(r)) == (x <= y) for r, (x, y) in zip(results, pairs))
+    calls = alice._coalescer().stats["calls"] + bob._coalescer().stats["calls"]
+    print(f"[sessions] {sessions} concurrent single comparisons in {dt * 1e3:.0f} ms through {calls} batched library calls; all correct: {ok}")
+
+
 async def batched(paillier: Paillier, dgk: DGK, count: int = 2048) -> None:
     l = 16
     dev = paillier.engine.device
@@ -65,6 +82,7 @@ async def batched(paillier: Paillier, dgk: DGK, count: int = 2048) -> None:
 
 async def main() -> None:
     paillier, dgk = await single_comparison()
+    await concurrent_singles(paillier, dgk)
     await batched(paillier, dgk)
 
 

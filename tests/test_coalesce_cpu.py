@@ -169,3 +169,31 @@ def test_a_step_runs_the_moment_every_session_in_flight_waits_in_it():
     out, lone = asyncio.run(go())
     assert out == [(10 * i, 10 * (i + 100)) for i in range(5)] and lone == (90, 1090)
     assert calls == [[0, 1, 2, 3, 4], [100, 101, 102, 103, 104], [9], [109]]
+
+
+def test_the_linger_restarts_after_every_straggler():
+    """Requests that trickle in over a transport -- each less than linger_s after the one before, the whole burst longer than linger_s --
+    still share ONE call: the wait for stragglers starts again after every arrival (it used to run once per queue: the second
+    straggler found a queue that had lingered already and was executed without the third); a gap longer than linger_s cuts."""
+    calls = []
+
+    def run(items):
+        calls.append(list(items))
+        return items
+
+    async def trickle(co, gaps):
+        async def one(i, at):
+            await asyncio.sleep(at)
+            return await co.submit("k", run, i)
+
+        at, jobs = 0.0, []
+        for i, g in enumerate(gaps):
+            at += g
+            jobs.append(one(i, at))
+        return await asyncio.gather(*jobs)
+
+    assert asyncio.run(trickle(StepCoalescer(linger_s=0.08), [0, 0.03, 0.03, 0.03, 0.03, 0.03])) == list(range(6))
+    assert calls == [[0, 1, 2, 3, 4, 5]]
+    calls.clear()
+    asyncio.run(trickle(StepCoalescer(linger_s=0.05), [0, 0.01, 0.01, 0.3, 0.01]))
+    assert calls == [[0, 1, 2], [3, 4]]
