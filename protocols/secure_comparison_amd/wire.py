@@ -53,6 +53,8 @@ MAGIC = b"SCB1"
 _DTYPES = {0: (torch.int32, np.dtype("<i4")), 1: (torch.int64, np.dtype("<i8")), 2: (torch.uint8, np.dtype("u1"))}
 _CODES = {t: c for c, (t, _) in _DTYPES.items()}
 MAX_NDIM = 4
+MAX_SCHEME_DOCUMENT = 1 << 16
+MAX_WINDOW_FROM_PEER = 16
 STATS = {"pack_s": 0.0, "unpack_s": 0.0, "bytes": 0, "device_arrays": 0}
 
 
@@ -493,11 +495,23 @@ def pack_public_schemes(paillier, dgk) -> bytes:
 def unpack_public_schemes(buf: bytes, engine=None):
     from .schemes import DGK, Paillier
 
-    doc = json.loads(bytes(buf).decode())
-    d = doc["dgk"]
+    raw = bytes(_as_view(buf)[:MAX_SCHEME_DOCUMENT + 1])
+    if len(raw) > MAX_SCHEME_DOCUMENT:               # (five integers of the largest supported keys are ~10 KB of hex)
+        raise ValueError("scheme document too large")
+    try:
+        doc = json.loads(raw.decode())
+        d = doc["dgk"]
+        int(doc["paillier"]["n"], 16), [int(d[k], 16) for k in ("n", "g", "h", "u")], int(d["t"]), int(d["randomizer_bits"]), int(d["fixed_base_window"])
+    except (KeyError, TypeError, AttributeError, UnicodeDecodeError, json.JSONDecodeError) as exc:
+        raise ValueError(f"malformed scheme document: {exc!r}") from None
+    n_dgk, rbits = int(d["n"], 16), int(d["randomizer_bits"])
+    if not 1 <= rbits <= 2 * n_dgk.bit_length():
+        raise ValueError(f"scheme document asks for {rbits}-bit DGK randomizers")
+    # the sender's table window is a hint about ITS memory: a peer does not get to size this party's tables (window 20 is 6 GB at
+    # 2048 bits; 16 costs 1.4 % of a step and 0.7 GB).  A party that wants more pre-sets its scheme objects.
+    window = max(1, min(int(d["fixed_base_window"]), MAX_WINDOW_FROM_PEER))
     return (Paillier(int(doc["paillier"]["n"], 16), engine=engine),
-            DGK(int(d["n"], 16), int(d["g"], 16), int(d["h"], 16), int(d["u"], 16), d["t"], engine=engine,
-                randomizer_bits=d["randomizer_bits"], fixed_base_window=d["fixed_base_window"]))
+            DGK(n_dgk, int(d["g"], 16), int(d["h"], 16), int(d["u"], 16), int(d["t"]), engine=engine, randomizer_bits=rbits, fixed_base_window=window))
 
 
 # ---- messages of the ONE-comparison protocol as bytes -----------------------------------------------------------------------------------

@@ -303,3 +303,27 @@ def test_forged_plane_header_is_refused_before_anything_is_allocated():
     planes_t = torch.arange(24, dtype=torch.int32).reshape(4, 2, 3)
     got = wire.unpack_many(bytes(wire.pack_many(d, planes_t)), "cpu", expect=2, planes_of_one=True)
     assert torch.equal(got[0], d) and torch.equal(got[1], planes_t) and got[1].data_ptr() == got[0].data_ptr() + 24
+
+
+def test_scheme_documents_from_a_peer_are_bounded(keys):
+    """wire.unpack_public_schemes: what arrives is a small JSON document of hex integers; anything else is a ValueError before a scheme
+    object exists, and the sender's fixed-base window -- a statement about ITS memory -- cannot size this party's tables."""
+    import json
+
+    od, osk = oracle_dgk(keys, "dgk_tiny_l16"), oracle_paillier(keys, 1024)
+    eng = OracleEngine()
+    good = wire.pack_public_schemes(Paillier(osk.n, engine=eng), DGK(od.n, od.g, od.h, od.u, od.t, engine=eng, randomizer_bits=50, fixed_base_window=20))
+    pai, dgk = wire.unpack_public_schemes(good, eng)
+    assert pai.public_key.n == osk.n and dgk.public_key.h == od.h and dgk.randomizer_bits == 50
+    assert dgk.fixed_base_window == wire.MAX_WINDOW_FROM_PEER == 16
+    doc = json.loads(good)
+    for mutate in (lambda d: d["dgk"].pop("h"), lambda d: d["dgk"].update(n="zz"), lambda d: d["dgk"].update(randomizer_bits=10 ** 9),
+                   lambda d: d["dgk"].update(randomizer_bits=0), lambda d: d.pop("paillier"), lambda d: d["dgk"].update(fixed_base_window=None),
+                   lambda d: d["paillier"].update(n=7)):
+        bad = json.loads(json.dumps(doc))
+        mutate(bad)
+        with pytest.raises(ValueError):
+            wire.unpack_public_schemes(json.dumps(bad).encode(), eng)
+    for raw in (b"", b"[1, 2]", b"\xff\xfe", good + b" " * (1 << 16)):
+        with pytest.raises(ValueError):
+            wire.unpack_public_schemes(raw, eng)
