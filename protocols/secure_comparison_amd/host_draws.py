@@ -18,8 +18,22 @@ from __future__ import annotations
 
 import os
 import secrets
+import weakref
 
 import numpy as np
+
+
+_instances: "weakref.WeakSet[HostDraws]" = weakref.WeakSet()
+
+
+def _forget_all_in_child() -> None:
+    # a forked child must never hand out the values its parent still holds in its buffers: a randomizer used twice gives the
+    # difference of two plaintexts away (`secrets` reads the OS generator per call and has no such state)
+    for d in list(_instances):
+        d.forget()
+
+
+os.register_at_fork(after_in_child=_forget_all_in_child)
 
 
 class HostDraws:
@@ -33,6 +47,13 @@ class HostDraws:
     def __init__(self, refill=None) -> None:
         self._refill = refill if refill is not None else os.urandom
         self._buf, self._at = b"", 0
+        _instances.add(self)
+
+    def forget(self) -> None:
+        """Drop everything drawn ahead (the buffered stream and the pools)."""
+        self._buf, self._at = b"", 0
+        for name in ("_bits_pools", "_below_pools", "_perm_pools"):
+            self.__dict__.pop(name, None)
 
     @classmethod
     def from_engine(cls, engine) -> "HostDraws":

@@ -197,3 +197,26 @@ def test_the_linger_restarts_after_every_straggler():
     calls.clear()
     asyncio.run(trickle(StepCoalescer(linger_s=0.05), [0, 0.01, 0.01, 0.3, 0.01]))
     assert calls == [[0, 1, 2], [3, 4]]
+
+
+def test_a_forked_child_does_not_repeat_its_parents_draws():
+    """HostDraws buffers a megabyte of the generator's stream and pools values ahead: after a fork the child's copy of all that is
+    dropped (os.register_at_fork), so parent and child never hand out the same randomizer."""
+    import multiprocessing as mp
+
+    from protocols.secure_comparison_amd.host_draws import HostDraws
+
+    d = HostDraws()
+    d.randbelow(1 << 200), d.bits_rows(100, 3), d.below_rows_nonzero((1 << 40) + 15, 3), d.permutation(9)     # buffers and pools are warm
+
+    def child(q):
+        q.put((d.randbelow(1 << 200), d.bits_rows(100, 2).tolist(), d.below_rows_nonzero((1 << 40) + 15, 2).tolist(), d.permutation(9)))
+
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    p = ctx.Process(target=child, args=(q,))
+    p.start()
+    theirs = q.get(timeout=60)
+    p.join(30)
+    mine = (d.randbelow(1 << 200), d.bits_rows(100, 2).tolist(), d.below_rows_nonzero((1 << 40) + 15, 2).tolist(), d.permutation(9))
+    assert theirs[0] != mine[0] and theirs[1] != mine[1] and theirs[2] != mine[2]
