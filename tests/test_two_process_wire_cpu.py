@@ -303,3 +303,49 @@ def test_session_messages_as_bytes_are_checked(keys):
     other = Paillier(oracle_paillier(keys, 2048).n, engine=eng)
     with pytest.raises(ValueError, match="word"):
         wire.unpack_session_message(good, other, dgk2)
+
+
+def test_mutated_session_messages_never_escape_as_anything_but_valueerror(keys):
+    """Two thousand random mutations (bit flips, truncations, insertions, spliced headers) of valid one-comparison messages: each either
+    parses into ciphertexts of this party's schemes or raises ValueError -- no other exception, no object bound to anything else."""
+    from _oracle_engine import OracleEngine
+    from protocols.secure_comparison_amd import DGK, DGKCiphertext, Paillier, PaillierCiphertext, wire
+
+    osk, od = oracle_paillier(keys, 1024), oracle_dgk(keys, "dgk_tiny_l16")
+    eng = OracleEngine()
+    pai, dgk = Paillier(osk.n, engine=eng), DGK(od.n, od.g, od.h, od.u, od.t, engine=eng, randomizer_bits=50)
+    rng = random.Random(77)
+    P = lambda: PaillierCiphertext(rng.randrange(osk.n * osk.n), pai)  # noqa: E731
+    D = lambda: DGKCiphertext(rng.randrange(od.n), dgk)  # noqa: E731
+    seeds = [wire.pack_session_message(m, pai, dgk) for m in (P(), (D(), [D() for _ in range(L)]), [D() for _ in range(L + 1)], (P(), P(), P()))]
+
+    def leaves(m):
+        return [x for c in m for x in leaves(c)] if isinstance(m, (list, tuple)) else [m]
+
+    parsed = refused = 0
+    for _ in range(2000):
+        b = bytearray(rng.choice(seeds))
+        for _ in range(rng.randrange(1, 4)):
+            kind = rng.randrange(5)
+            if kind == 0 and b:
+                b[rng.randrange(min(len(b), 40))] ^= 1 << rng.randrange(8)           # the header and shape bytes
+            elif kind == 1 and b:
+                b[rng.randrange(len(b))] = rng.randrange(256)
+            elif kind == 2:
+                del b[rng.randrange(len(b) + 1):]
+            elif kind == 3:
+                at = rng.randrange(len(b) + 1)
+                b[at:at] = bytes(rng.randrange(256) for _ in range(rng.choice([1, 4, 128])))
+            else:
+                other = rng.choice(seeds)
+                b[:rng.randrange(8, 24)] = other[:rng.randrange(8, 24)]
+        try:
+            out = wire.unpack_session_message(bytes(b), pai, dgk)
+        except ValueError:
+            refused += 1
+            continue
+        parsed += 1
+        for c in leaves(out):
+            assert (type(c) is PaillierCiphertext and c.scheme is pai) or (type(c) is DGKCiphertext and c.scheme is dgk)
+            c.peek_value()
+    assert parsed > 50 and refused > 500, (parsed, refused)
