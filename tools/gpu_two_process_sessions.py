@@ -148,8 +148,13 @@ def parent(args):
         prof = ["--profile", args.profile] if args.profile else []
         bob = subprocess.Popen(common + ["--role", "keyholder"])            # children started fresh, by a parent that has not touched the GPU
         alice = subprocess.Popen(common + prof + ["--role", "initiator"])
-        rc_a = alice.wait(timeout=1100)
-        rc_b = bob.wait(timeout=120)
+        try:
+            rc_a = alice.wait(timeout=1100)
+            rc_b = bob.wait(timeout=120)
+        finally:
+            for child in (alice, bob):                  # never leave a player behind on the GPU (ended by PID)
+                if child.poll() is None:
+                    child.kill()
         if rc_a or rc_b:
             raise SystemExit(f"two-process run failed: initiator {rc_a}, keyholder {rc_b}")
 
