@@ -502,10 +502,12 @@ def concurrent_sessions_leg(torch, eng, keys, sessions: int = 1024, shapes=(("pa
         for i in range(0, sessions, 8):
             pairs[i] = (pairs[i][0], pairs[i][0])           # equal inputs in every eighth session
 
-        def run(n: int, coalesce: bool):
+        def run(n: int, coalesce: bool, pause_collector: bool = True):
             comm = InMemoryCommunicator()
             alice, bob = Initiator(l, comm, "keyholder", bob_p.public_copy(), alice_d), KeyHolder(l, comm.peer(), "initiator", bob_p, bob_d)
             alice.coalesce_sessions = bob.coalesce_sessions = coalesce
+            if not pause_collector:
+                alice.coalesce_pause_collector_s = bob.coalesce_pause_collector_s = 0
 
             async def go():
                 a = [asyncio.ensure_future(alice.perform_secure_comparison(x, y)) for x, y in pairs[:n]]
@@ -527,19 +529,21 @@ def concurrent_sessions_leg(torch, eng, keys, sessions: int = 1024, shapes=(("pa
         dt = sorted(r[0] for r in runs)[1]
         from protocols.secure_comparison_amd.coalesce import quiet_collector
 
-        with quiet_collector():                            # what an application serving such bursts would do (a process-wide setting: never the library's choice)
+        with quiet_collector():                            # what an application serving such bursts all day might do on top
             quiet = [run(sessions, True) for _ in range(3)]
         dt_quiet = sorted(r[0] for r in quiet)[1]
+        untouched = [run(sessions, True, pause_collector=False) for _ in range(3)]
+        dt_untouched = sorted(r[0] for r in untouched)[1]
         n_un = min(32, sessions)
         run(4, False)
         dt_un, ok_un, _ = run(n_un, False)
         row = {"workload": "%d concurrent perform_secure_comparison sessions, l=%d, %s + %s" % (sessions, l, pname, dname),
                "value": sessions / dt, "unit": "comparisons/s", "seconds": dt, "sessions": sessions,
-               "value_quiet_collector": sessions / dt_quiet,
+               "value_quiet_collector": sessions / dt_quiet, "value_collector_untouched": sessions / dt_untouched,
                "batched_calls": {"initiator": runs[-1][2][0]["calls"], "keyholder": runs[-1][2][1]["calls"], "largest_batch": runs[-1][2][0]["largest"]},
                "seconds_in_batched_calls": {"initiator": {k: round(v, 4) for k, v in runs[-1][2][0]["seconds"].items()},
                                             "keyholder": {k: round(v, 4) for k, v in runs[-1][2][1]["seconds"].items()}},
-               "uncoalesced": {"value": n_un / dt_un, "sessions": n_un}, "correct": all(r[1] for r in runs + quiet) and ok_un}
+               "uncoalesced": {"value": n_un / dt_un, "sessions": n_un}, "correct": all(r[1] for r in runs + quiet + untouched) and ok_un}
         if cpu_run is not None:
             try:
                 cb = cpu_run(pname, dname)
@@ -552,9 +556,11 @@ def concurrent_sessions_leg(torch, eng, keys, sessions: int = 1024, shapes=(("pa
         out.append(row)
     return {"shapes": out,
             "note": "wall clock of asyncio.run over all sessions of both players in one process and event loop (Python object handling included), median of 3; "
-                    "every session draws its own randomness and sends / receives its own four messages; value_quiet_collector: the same three runs inside "
-                    "coalesce.quiet_collector() -- CPython's cyclic garbage collector frozen and its generation-0 threshold raised for the burst, which an "
-                    "application serving thousands of concurrent sessions would do and the library never does by itself; cpu_oracle = oracle.compare on the box's host cores "
+                    "every session draws its own randomness and sends / receives its own four messages; value: the library's default -- CPython's cyclic garbage "
+                    "collector paused from the first session of a burst until the last has left, 0.5 s at most (coalesce._CollectorPause; "
+                    "Initiator / KeyHolder.coalesce_pause_collector_s); value_collector_untouched: the same runs with that set to 0; value_quiet_collector: "
+                    "inside coalesce.quiet_collector() as well (the interpreter's existing objects frozen out of the collector's passes, generation-0 "
+                    "threshold raised: an application's choice); cpu_oracle = oracle.compare on the box's host cores "
                     "(same key sizes and l, multiprocessing); informational, never `value`"}
 
 

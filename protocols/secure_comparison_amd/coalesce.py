@@ -18,12 +18,61 @@ from __future__ import annotations
 import asyncio
 import contextlib
 import gc
+import threading
 import time
 from typing import Any, Callable, Sequence
 
 import numpy as np
 
 from .limbs import RowBlock
+
+
+class _CollectorPause:
+    """The cyclic garbage collector, paused for the start of a burst of sessions -- process-wide state, so kept in ONE place for every
+    coalescer of the process (the two players of a test or a bench share an interpreter).
+
+    A thousand sessions in flight keep ~10^5 small container objects alive (tasks, futures, messages of l + 1 ciphertext objects).
+    With CPython's default thresholds the collector examines them -- and, in its full passes, everything torch and numpy imported --
+    a few hundred times per burst, and finds nothing: the objects die by reference count when their sessions end.  Measured on the
+    GPU box: 5.8 k -> 7.9 k comparisons/s at l = 32 / 2048-bit, 7.8 k -> 12.9 k at l = 16 / 1024-bit.  So the collector is switched
+    off when the first session of a burst enters and on again when the last one leaves -- or `limit_s` after the first one entered,
+    whichever comes first: a server whose sessions never drain loses nothing but the first `limit_s` of collection per burst, and
+    cyclic garbage made meanwhile is collected right afterwards.  Nothing happens when the application has the collector off
+    already, and `pause_collector_s = 0` on a player keeps the library's hands off it."""
+
+    def __init__(self) -> None:
+        self._lock = threading.Lock()
+        self.holders = 0            # sessions in flight, over every coalescer that asked for the pause
+        self.owned = False          # the collector is off because of us
+        self.expired = False        # this burst has used up its limit: not again before every session has left
+        self.since = self.limit = 0.0
+
+    def enter(self, limit_s: float) -> None:
+        with self._lock:
+            self.holders += 1
+            if self.holders == 1:
+                self.expired = False
+            if limit_s > 0 and not self.owned and not self.expired and gc.isenabled():
+                gc.disable()
+                self.owned, self.since, self.limit = True, time.monotonic(), limit_s
+
+    def leave(self) -> None:
+        with self._lock:
+            self.holders -= 1
+            if self.owned and self.holders <= 0:
+                gc.enable()
+                self.owned = False
+
+    def check(self) -> None:
+        """Called from inside a burst (after every batched call): give the collector back once the burst has had its share."""
+        if self.owned and time.monotonic() - self.since > self.limit:
+            with self._lock:
+                if self.owned:
+                    gc.enable()
+                    self.owned, self.expired = False, True
+
+
+_collector_pause = _CollectorPause()
 
 
 class _Queue:
@@ -48,9 +97,10 @@ class StepCoalescer:
     protocol: tools/gpu_two_process_sessions.py).  The batched call itself runs synchronously on the event loop's thread, like every
     GPU call of the single path."""
 
-    def __init__(self, max_batch: int = 4096, linger_s: float = 0.0) -> None:
+    def __init__(self, max_batch: int = 4096, linger_s: float = 0.0, pause_collector_s: float = 0.5) -> None:
         self.max_batch = max(1, int(max_batch))
         self.linger_s = float(linger_s)
+        self.pause_collector_s = float(pause_collector_s)     # _CollectorPause: 0 = never touch the garbage collector
         self._queues: dict[str, _Queue] = {}
         self.active = 0          # sessions of the player in flight (session())
         self.stats = {"calls": 0, "items": 0, "largest": 0, "fallbacks": 0, "seconds": {}}     # seconds: wall clock inside the batched calls, per step
@@ -59,10 +109,12 @@ class StepCoalescer:
     def session(self):
         """Brackets one session of the player: the coalescer then knows how many sessions can still arrive at a step."""
         self.active += 1
+        _collector_pause.enter(self.pause_collector_s)
         try:
             yield
         finally:
             self.active -= 1
+            _collector_pause.leave()
 
     async def submit(self, kind: str, run: Callable[[list], Sequence], item: Any, first: bool = False) -> Any:
         """Queue `item` for the step `kind`; `run(items)` makes ONE batched call for a list of such items and returns one result per
@@ -140,6 +192,7 @@ class StepCoalescer:
             if gc_was_on:
                 gc.enable()
         self.stats["seconds"][kind] = self.stats["seconds"].get(kind, 0.0) + time.perf_counter() - t0
+        _collector_pause.check()
         for fut, (ok, value) in zip(futures, outcomes):
             if fut.done():                          # the session was cancelled while it waited
                 continue
@@ -206,8 +259,9 @@ def quiet_collector(generation0: int = 1_000_000):
     generation-0 threshold is raised (a collection per `generation0` container allocations instead of per 700) and the objects that
     exist already are frozen out of its passes; both are restored on exit.  A thousand sessions in flight keep ~10^5 small container
     objects alive (messages of l + 1 ciphertext objects each); CPython's default thresholds then walk them -- and everything torch
-    and numpy imported -- a few hundred times per burst: measured 4.4 k -> 6.8-8.5 k comparisons/s at l = 32 / 2048-bit.  The library
-    never does this by itself (it is a process-wide setting)."""
+    and numpy imported -- a few hundred times per burst.  The library's own default is narrower (_CollectorPause above: the collector off
+    for the start of a burst, half a second at most, nothing frozen, no threshold changed) and gets within 4 % of this; freezing the
+    interpreter's objects and changing thresholds for as long as the application likes is the application's decision."""
     old = gc.get_threshold()
     gc.collect()
     gc.freeze()

@@ -46,6 +46,10 @@ class Initiator:
     coalesce_sessions = True
     coalesce_max_batch = 4096
     coalesce_linger_s = 0.0
+    # While sessions are in flight the cyclic garbage collector is paused, for at most this many seconds from the first session of
+    # a burst (coalesce._CollectorPause: it finds nothing to collect among a burst's ~10^5 live message objects and costs a third to
+    # half of the burst); 0 = the library never touches the collector.
+    coalesce_pause_collector_s = 0.5
 
     def __init__(self, l_maximum_bit_length: int, communicator: Communicator | None = None, other_party: str = "",
                  scheme_paillier: Paillier | None = None, scheme_dgk: DGK | None = None, session_id: int = 0) -> None:
@@ -153,8 +157,8 @@ class Initiator:
         from .coalesce import StepCoalescer
 
         co = self.__dict__.get("_step_coalescer")
-        if co is None or co.max_batch != self.coalesce_max_batch or co.linger_s != self.coalesce_linger_s:
-            co = self.__dict__["_step_coalescer"] = StepCoalescer(self.coalesce_max_batch, self.coalesce_linger_s)
+        if co is None or (co.max_batch, co.linger_s, co.pause_collector_s) != (self.coalesce_max_batch, self.coalesce_linger_s, self.coalesce_pause_collector_s):
+            co = self.__dict__["_step_coalescer"] = StepCoalescer(self.coalesce_max_batch, self.coalesce_linger_s, self.coalesce_pause_collector_s)
         return co
 
     def _draws(self):

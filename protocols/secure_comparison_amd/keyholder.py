@@ -37,6 +37,7 @@ class KeyHolder:
     coalesce_sessions = True      # see Initiator.coalesce_sessions
     coalesce_max_batch = 4096
     coalesce_linger_s = 0.0
+    coalesce_pause_collector_s = 0.5      # see Initiator.coalesce_pause_collector_s
 
     def __init__(self, l_maximum_bit_length: int, communicator: Communicator | None = None, other_party: str = "",
                  scheme_paillier: Paillier | None = None, scheme_dgk: DGK | None = None, session_id: int = 0) -> None:
@@ -121,8 +122,8 @@ class KeyHolder:
         from .coalesce import StepCoalescer
 
         co = self.__dict__.get("_step_coalescer")
-        if co is None or co.max_batch != self.coalesce_max_batch or co.linger_s != self.coalesce_linger_s:
-            co = self.__dict__["_step_coalescer"] = StepCoalescer(self.coalesce_max_batch, self.coalesce_linger_s)
+        if co is None or (co.max_batch, co.linger_s, co.pause_collector_s) != (self.coalesce_max_batch, self.coalesce_linger_s, self.coalesce_pause_collector_s):
+            co = self.__dict__["_step_coalescer"] = StepCoalescer(self.coalesce_max_batch, self.coalesce_linger_s, self.coalesce_pause_collector_s)
         return co
 
     def _draws(self):

@@ -220,3 +220,39 @@ def test_a_forked_child_does_not_repeat_its_parents_draws():
     p.join(30)
     mine = (d.randbelow(1 << 200), d.bits_rows(100, 2).tolist(), d.below_rows_nonzero((1 << 40) + 15, 2).tolist(), d.permutation(9))
     assert theirs[0] != mine[0] and theirs[1] != mine[1] and theirs[2] != mine[2]
+
+
+def test_the_collector_pauses_for_the_start_of_a_burst_and_no_longer():
+    """coalesce._CollectorPause: off when the first session of a burst enters, on again when the last one leaves -- or limit_s after
+    the first entered, and then not again before every session has left; never touched when the application had it off or when
+    pause_collector_s is 0; two coalescers of one process share the one state."""
+    import gc
+    import time
+
+    seen = {}
+
+    async def burst(cos, hold_s=0.0, probe=None):
+        async def session(co, i):
+            with co.session():
+                seen.setdefault("inside", []).append(gc.isenabled())
+                await co.submit("k", lambda items: items, i)
+                if hold_s:
+                    await asyncio.sleep(hold_s)
+                    await co.submit("k2", lambda items: items, i)       # (the check runs after a batched call)
+                    await asyncio.sleep(0)
+                    seen.setdefault("late", []).append(gc.isenabled())
+        await asyncio.gather(*(session(co, i) for i in range(4) for co in cos))
+
+    assert gc.isenabled()
+    try:
+        asyncio.run(burst([StepCoalescer(), StepCoalescer()]))
+        assert seen.pop("inside") == [False] * 8 and gc.isenabled()
+        asyncio.run(burst([StepCoalescer(pause_collector_s=0.05)], hold_s=0.12))
+        assert seen.pop("inside") == [False] * 4 and seen.pop("late") == [True] * 4 and gc.isenabled()
+        asyncio.run(burst([StepCoalescer(pause_collector_s=0)]))
+        assert seen.pop("inside") == [True] * 4 and gc.isenabled()
+        gc.disable()                                                   # the application's own choice stays
+        asyncio.run(burst([StepCoalescer()]))
+        assert seen.pop("inside") == [False] * 4 and not gc.isenabled()
+    finally:
+        gc.enable()

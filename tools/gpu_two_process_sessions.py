@@ -33,6 +33,7 @@ def parse():
     ap.add_argument("--pbits", type=int, default=2048)
     ap.add_argument("--linger-ms", type=float, default=2.0)
     ap.add_argument("--quiet-gc", type=int, default=0)
+    ap.add_argument("--pause-gc", type=float, default=0.5)         # the players' coalesce_pause_collector_s (0: collector untouched)
     ap.add_argument("--profile", default="")
     return ap.parse_args()
 
@@ -67,6 +68,7 @@ async def keyholder(args):
     comm = await StreamCommunicator.accept_unix(args.socket, engine=eng)
     bob = KeyHolder(args.l, comm, "initiator", bob_p, bob_d)
     bob.coalesce_linger_s = args.linger_ms / 1e3
+    bob.coalesce_pause_collector_s = args.pause_gc
     with _collector(args):
         for _ in range(args.bursts + 1):                      # one warm-up burst, then the timed ones
             await asyncio.gather(*(bob.perform_secure_comparison() for _ in range(args.sessions)))
@@ -90,6 +92,7 @@ async def initiator(args):
     comm = await StreamCommunicator.open_unix(args.socket, engine=eng, wait_s=300)
     alice = Initiator(args.l, comm, "keyholder")               # her schemes arrive over the wire
     alice.coalesce_linger_s = args.linger_ms / 1e3
+    alice.coalesce_pause_collector_s = args.pause_gc
     rng = random.Random(11)
     xs = [rng.randrange(1 << args.l) for _ in range(args.sessions)]
     ys = [xs[i] if i % 4 == 0 else rng.randrange(1 << args.l) for i in range(args.sessions)]
@@ -129,7 +132,7 @@ async def initiator(args):
     spans.sort()
     print(json.dumps({"two_process_sessions": True, "value": args.sessions * args.bursts / sum(spans), "unit": "comparisons/s",
                       "best_burst_value": args.sessions / spans[0], "sessions": args.sessions, "bursts": args.bursts, "l": args.l,
-                      "paillier_bits": args.pbits, "linger_ms": args.linger_ms, "quiet_collector": bool(args.quiet_gc),
+                      "paillier_bits": args.pbits, "linger_ms": args.linger_ms, "quiet_collector": bool(args.quiet_gc), "pause_collector_s": args.pause_gc,
                       "seconds_per_burst": {"min": spans[0], "median": spans[len(spans) // 2], "max": spans[-1]},
                       "bytes_sent_by_the_initiator_per_comparison": sent / (args.sessions * args.bursts),
                       "initiator_batched_calls": {"calls": st["calls"], "items": st["items"], "largest": st["largest"], "fallbacks": st["fallbacks"],
@@ -144,7 +147,7 @@ def parent(args):
     with tempfile.TemporaryDirectory() as td:
         sock = os.path.join(td, "sc.sock")
         common = [sys.executable, os.path.abspath(__file__), "--socket", sock, "--sessions", str(args.sessions), "--bursts", str(args.bursts),
-                  "--l", str(args.l), "--pbits", str(args.pbits), "--linger-ms", str(args.linger_ms), "--quiet-gc", str(args.quiet_gc)]
+                  "--l", str(args.l), "--pbits", str(args.pbits), "--linger-ms", str(args.linger_ms), "--quiet-gc", str(args.quiet_gc), "--pause-gc", str(args.pause_gc)]
         prof = ["--profile", args.profile] if args.profile else []
         bob = subprocess.Popen(common + ["--role", "keyholder"])            # children started fresh, by a parent that has not touched the GPU
         alice = subprocess.Popen(common + prof + ["--role", "initiator"])
