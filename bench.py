@@ -657,6 +657,24 @@ class GpuRuntime:
         return Engine()
 
 
+class SharedGpuRehearsal(GpuRuntime):
+    """SC_BENCH_SHARE_GPU=1: every rank on GPU 0, gloo as the collective (it carries device tensors).  RCCL refuses two ranks on one
+    device, and the builder's boxes have one GPU: this is how the N > 1 control flow -- rank set-up, the per-step gather into the
+    persistent array, the rank check, the per-rank rows, rank 0's line -- meets the real engines and kernels before the first
+    multi-GPU run.  The line says so (`rehearsal`); it is never a scaling measurement."""
+
+    backend = "gloo"
+    rehearsal = "every rank on GPU 0, gloo instead of RCCL (SC_BENCH_SHARE_GPU=1): a rehearsal of the N > 1 control flow on real kernels, not a scaling measurement"
+
+    def check_device(self, rank: int, local_rank: int) -> None:
+        if not self.torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+        self.torch.cuda.set_device(0)
+
+    def dist_device(self, local_rank: int):
+        return None
+
+
 def main(argv=None, runtime=None, script: str | None = None) -> None:
     """runtime / script: the CPU dry run of the test tier passes its stand-in for GpuRuntime and its own path (the ranks a
     `--gpus N` parent starts must be the same program)."""
@@ -668,12 +686,12 @@ def main(argv=None, runtime=None, script: str | None = None) -> None:
         raise SystemExit("--gpus must be at least 1")
     if args.gpus > 1 and launcher.rank_env() is None:
         sys.exit(launcher.spawn_ranks(script or os.path.abspath(__file__), list(sys.argv[1:] if argv is None else argv), args.gpus,
-                                      need_gpus=runtime is None))
+                                      need_gpus=runtime is None and not os.environ.get("SC_BENCH_SHARE_GPU")))
     rank, local_rank, world = launcher.expect_world(args.gpus)
 
     import torch
 
-    rt = runtime if runtime is not None else GpuRuntime(torch)
+    rt = runtime if runtime is not None else (SharedGpuRehearsal(torch) if os.environ.get("SC_BENCH_SHARE_GPU") else GpuRuntime(torch))
     rt.check_device(rank, local_rank)
     dist = None
     if world > 1 or args.force_dist:
@@ -994,6 +1012,7 @@ def measure(args, torch, dist, rank: int, world: int, full: bool, rt=None):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 (29-bit limbs held in u32, 32x32+64->64 multiply-accumulate)",
             "data": "synthetic", "rccl_ranks": rccl_ranks, "rank_devices": devices, "c_abi_gather": c_abi_gather,
+            **({"rehearsal": rt.rehearsal} if getattr(rt, "rehearsal", None) else {}),
             "step_ms": {"min": step_ms[0], "median": step_ms[len(step_ms) // 2], "max": step_ms[-1],
                         "note": "per-step device time between events on the caller's stream inside the timed region (no synchronisation added)"},
             "per_rank": per_rank,

@@ -164,3 +164,27 @@ def test_concurrent_single_comparisons_between_two_os_processes():
     assert d["two_process_sessions"] and d["rows_checked"] == 48 and d["rows_decrypting_to_x_le_y"] == 48
     for side in ("initiator_batched_calls", "keyholder_batched_calls"):
         assert d[side]["items"] == 3 * 48 * 3 and d[side]["fallbacks"] == 0 and d[side]["calls"] < d[side]["items"] // 4, d[side]
+
+
+def test_two_ranks_rehearse_the_multi_gpu_bench_on_one_gpu():
+    """`SC_BENCH_SHARE_GPU=1 python bench.py --gpus 2`: two OS-process ranks on GPU 0 with gloo as the collective (RCCL refuses two ranks
+    on one device, this box has one GPU).  Everything else is the N > 1 path as the driver will run it on eight GPUs -- the parent
+    spawns the ranks, every rank runs its B comparisons through the real kernels, the per-step gather fills the persistent array
+    inside the timed region, every rank decrypts ITS block of the gathered array, rank 0's line carries a row per rank -- and the
+    line says that it is a rehearsal."""
+    import json
+    import subprocess
+
+    from conftest import ROOT
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["SC_BENCH_SHARE_GPU"] = "1"
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "1024", "--l", "16", "--dgk", "dgk_2048_l16", "--fb-window", "8",
+                         "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
+    assert cp.returncode == 0, cp.stderr[-3000:]
+    line = json.loads([ln for ln in cp.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["rank_devices"] == [0, 0] and "rehearsal" in line
+    assert line["value"] > 0 and line["scaling"] == "weak" and line["config"]["batch_per_gpu"] == 1024
+    rows = line["per_rank"]
+    assert [r["rank"] for r in rows] == [0, 1] and all(r["solo_step_ms"] > 0 and r["launch_ms_before"] > 0 for r in rows)
+    assert line["weak_scaling_efficiency"] > 0            # (no meaning here: the ranks' solo steps compete for the one GPU)
