@@ -1,3 +1,8 @@
+"""Dev probe: do gloo's collectives carry DEVICE tensors when two ranks share one GPU?  (They do on this image -- which is what
+bench.py's SC_BENCH_SHARE_GPU rehearsal of the N > 1 path rests on; RCCL refuses two ranks on one device.)
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 tools/gpu_gloo_probe.py
+"""
 import os, sys, torch, torch.distributed as dist
 rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
